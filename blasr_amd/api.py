@@ -1,0 +1,133 @@
+"""Host-side handle over the C-ABI: one Context per (worker, GPU), as include/gba.h asks.
+
+`Context.refine_host` takes numpy batches (gba_submit / gba_wait, H2D + D2H inside);
+`Context.refine_device` takes torch CUDA tensors that already live in HBM
+(gba_submit_device).  torch is used for device memory and streams only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (BLOCK_DT, PAIR_RESULT_DT, Batch, Config, GbaError, Results, Scoring, Timing)
+
+
+def make_scoring(match=-5, mismatch=6, n_score=0, ins=5, dele=4, indel=5, band=10, max_band=250,
+                 mode=_lib.MODE_LINEAR, tie_break=_lib.TIE_DIAG_LEFT_UP, affine_open=10,
+                 affine_extend=0, stats_affine=0, stats_affine_open=0, stats_affine_extend=0,
+                 kband_k=0, sub=None):
+    """gba_scoring with BLASR's defaults: SMRTDistanceMatrix-like match/mismatch
+    (iblasr/RegisterBlasrOptions.h:358-360), the refine scorer's gap costs
+    (iblasr/BlasrUtilsImpl.hpp:630-631 read as ins=5, del=4), rescoring with indel=5 both
+    ways (:633-634), guidedAlignBandSize=10 (iblasr/MappingParameters.h:336)."""
+    s = Scoring()
+    for a in range(5):
+        for b in range(5):
+            if sub is not None:
+                v = int(sub[a][b])
+            elif a == 4 or b == 4:
+                v = n_score
+            else:
+                v = match if a == b else mismatch
+            s.sub[a][b] = v
+    s.ins, s.dele = ins, dele
+    s.affine_open, s.affine_extend = affine_open, affine_extend
+    s.stats_ins, s.stats_del = indel, indel
+    s.stats_affine_open, s.stats_affine_extend = stats_affine_open, stats_affine_extend
+    s.band, s.max_band, s.mode, s.tie_break = band, max_band, mode, tie_break
+    s.kband_k, s.stats_affine = kband_k, stats_affine
+    return s
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    def __init__(self, device=0, timing=False, stream=None):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        cfg = Config(device, _lib.FLAG_TIMING if timing else 0, stream)
+        rc = self._L.gba_create(C.byref(self._h), C.byref(cfg))
+        if rc != _lib.OK:
+            raise GbaError(rc)
+        self.device = device
+
+    def close(self):
+        if self._h:
+            self._L.gba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow=()):
+        if rc != _lib.OK and rc not in allow:
+            raise GbaError(rc, self._L.gba_last_hip_error(self._h))
+        return rc
+
+    def set_scoring(self, scoring):
+        self._check(self._L.gba_set_scoring(self._h, C.byref(scoring)))
+        self.scoring = scoring
+
+    def timing(self):
+        t = Timing()
+        self._check(self._L.gba_get_timing(self._h, C.byref(t)))
+        return {f[0]: getattr(t, f[0]) for f in Timing._fields_}
+
+    # ---- host buffers in, host buffers out
+    def refine_host(self, batch, blocks_capacity=None):
+        """batch: dict of numpy arrays (see blasr_amd.synth.generate).  Returns
+        (pairs ndarray[PAIR_RESULT_DT], blocks ndarray[BLOCK_DT], rc)."""
+        n = int(batch["n_pairs"])
+        keep = {k: np.ascontiguousarray(batch[k], dtype=dt) for k, dt in (
+            ("q_arena", np.uint8), ("t_arena", np.uint8), ("blocks", BLOCK_DT),
+            ("q_off", np.uint64), ("t_off", np.uint64), ("blk_off", np.uint64),
+            ("q_len", np.uint32), ("t_len", np.uint32), ("n_blk", np.uint32))}
+        b = Batch(n, _ptr(keep["q_arena"]), _ptr(keep["q_off"]), _ptr(keep["q_len"]),
+                  _ptr(keep["t_arena"]), _ptr(keep["t_off"]), _ptr(keep["t_len"]),
+                  _ptr(keep["blocks"]), _ptr(keep["blk_off"]), _ptr(keep["n_blk"]),
+                  keep["q_arena"].size, keep["t_arena"].size, keep["blocks"].size)
+        self._check(self._L.gba_submit(self._h, C.byref(b)))
+        if blocks_capacity is None:
+            blocks_capacity = int(keep["q_len"].astype(np.uint64).sum()) + n
+        pairs = np.zeros(n, dtype=PAIR_RESULT_DT)
+        blocks = np.zeros(max(int(blocks_capacity), 1), dtype=BLOCK_DT)
+        r = Results(_ptr(pairs), _ptr(blocks), int(blocks_capacity), 0)
+        rc = self._check(self._L.gba_wait(self._h, C.byref(r)), allow=(_lib.E_NOSPACE,))
+        self.blocks_needed = int(r.blocks_needed)
+        return pairs, blocks[:min(self.blocks_needed, int(blocks_capacity))], rc
+
+    # ---- device-resident tensors
+    def refine_device(self, dbatch, out_pairs, out_blocks):
+        """dbatch: dict of torch CUDA tensors with the same keys as a host batch (uint8 arenas;
+        offsets/lengths as int64/int32 tensors holding the uint64/uint32 bit patterns; blocks as
+        an int32 tensor [n_blocks, 3]).  out_pairs: uint8 tensor of n*PAIR_RESULT_DT.itemsize
+        bytes; out_blocks: int32 tensor [capacity, 3].  Returns (rc, blocks_needed)."""
+        n = int(dbatch["n_pairs"])
+        b = Batch(n, dbatch["q_arena"].data_ptr(), dbatch["q_off"].data_ptr(), dbatch["q_len"].data_ptr(),
+                  dbatch["t_arena"].data_ptr(), dbatch["t_off"].data_ptr(), dbatch["t_len"].data_ptr(),
+                  dbatch["blocks"].data_ptr(), dbatch["blk_off"].data_ptr(), dbatch["n_blk"].data_ptr(),
+                  dbatch["q_arena"].numel(), dbatch["t_arena"].numel(), dbatch["blocks"].shape[0])
+        assert out_pairs.numel() * out_pairs.element_size() >= n * PAIR_RESULT_DT.itemsize
+        r = Results(out_pairs.data_ptr(), out_blocks.data_ptr(), out_blocks.shape[0], 0)
+        rc = self._check(self._L.gba_submit_device(self._h, C.byref(b), C.byref(r)), allow=(_lib.E_NOSPACE,))
+        return rc, int(r.blocks_needed)
+
+
+def to_device(batch, device="cuda:0"):
+    """Copy a host batch dict to torch CUDA tensors (bit patterns preserved)."""
+    import torch
+    d = {"n_pairs": int(batch["n_pairs"])}
+    for k in ("q_arena", "t_arena"):
+        d[k] = torch.from_numpy(np.ascontiguousarray(batch[k], dtype=np.uint8)).to(device)
+    for k in ("q_off", "t_off", "blk_off"):
+        d[k] = torch.from_numpy(np.ascontiguousarray(batch[k], dtype=np.uint64).view(np.int64)).to(device)
+    for k in ("q_len", "t_len", "n_blk"):
+        d[k] = torch.from_numpy(np.ascontiguousarray(batch[k], dtype=np.uint32).view(np.int32)).to(device)
+    blk = np.ascontiguousarray(batch["blocks"], dtype=BLOCK_DT)
+    d["blocks"] = torch.from_numpy(blk.view(np.uint32).reshape(-1, 3).view(np.int32)).to(device)
+    return d

@@ -1,0 +1,38 @@
+"""In-tree build of the native pieces: libgba.so (HIP, gfx950) and libgbasynth.so (C)."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIBGBA = os.path.join(_HERE, "libgba.so")
+SRC = os.path.join(_HERE, "csrc", "gba.hip")
+HDR = os.path.join(ROOT, "include", "gba.h")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_libgba(force=False, extra=()):
+    if force or _stale(LIBGBA, [SRC, HDR]):
+        cmd = ["hipcc"] + HIPCC_FLAGS + list(extra) + ["-o", LIBGBA, SRC]
+        subprocess.check_call(cmd)
+    return LIBGBA
+
+
+def build_all(force=False):
+    from . import synth
+    build_libgba(force)
+    synth.build(force)
+
+
+if __name__ == "__main__":
+    import sys
+    build_all(force="--force" in sys.argv)
+    print(LIBGBA)

@@ -1,0 +1,165 @@
+/*
+ * gba.h -- C ABI of libgba: guided banded alignment (BLASR refine stage) on MI355X.
+ *
+ * The reference has no FFI for this path: RefineAlignment calls header
+ * templates of libcpp directly (iblasr/BlasrUtilsImpl.hpp:705-732).  This header
+ * is the boundary a maintainer would bind instead; every entry point names the
+ * reference interface it replaces.  Plain pointers and sizes only.
+ *
+ * Threading: one gba_ctx per (host worker, GPU); a ctx is not thread-safe,
+ * different ctxs are independent (the reference's per-thread MappingBuffers,
+ * Blasr.cpp:771).  Errors are return codes (< 0); a bad pair never fails a batch,
+ * it gets a per-pair status (> 0) and is passed through untouched, like the
+ * empty-guide case at iblasr/BlasrUtilsImpl.hpp:681.
+ */
+#ifndef GBA_H
+#define GBA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GBA_VERSION 100   /* major*10000 + minor*100 + patch */
+
+/* return codes of the entry points */
+enum {
+    GBA_OK = 0,
+    GBA_E_INVALID = -1,      /* bad argument */
+    GBA_E_NOMEM = -2,        /* host or device allocation failed */
+    GBA_E_HIP = -3,          /* a HIP call failed; gba_last_hip_error() has the code */
+    GBA_E_NOSPACE = -4,      /* caller's block arena too small; gba_results.blocks_needed says how big */
+    GBA_E_UNSUPPORTED = -5,  /* scoring outside what the kernels implement */
+    GBA_E_STATE = -6         /* wait without submit, submit while a batch is in flight, ... */
+};
+
+/* per-pair status (gba_pair_result.status) */
+enum {
+    GBA_PAIR_OK = 0,
+    GBA_PAIR_EMPTY_GUIDE = 1,      /* no blocks: candidate left as it was (BlasrUtilsImpl.hpp:681) */
+    GBA_PAIR_BAD_GUIDE = 2,        /* blocks unordered, overlapping, empty or outside the sequences */
+    GBA_PAIR_UNREACHABLE = 3,      /* the band is disconnected: no path reaches the end cell */
+    GBA_PAIR_NOSPACE = 4,          /* blocks of this pair did not fit the caller's arena */
+    GBA_PAIR_END_OUT_OF_BAND = 5,  /* k-band: |t_len - q_len| > k */
+    GBA_PAIR_TOO_WIDE = 6,         /* a band row wider than the kernels support */
+    GBA_PAIR_TOO_LONG = 7          /* more DP rows or columns than the kernels support */
+};
+
+enum { GBA_MODE_LINEAR = 0,   /* replaces GuidedAlign,       BlasrUtilsImpl.hpp:713-716, :727-730 */
+       GBA_MODE_AFFINE = 1,   /* replaces AffineGuidedAlign, BlasrUtilsImpl.hpp:707-710, :721-724 */
+       GBA_MODE_KBAND  = 2 }; /* replaces KBandAlign(Global), BlasrUtilsImpl.hpp:657-661          */
+
+/* tie-break among equal candidates of the match state */
+enum { GBA_TIE_DIAG_LEFT_UP = 0, GBA_TIE_DIAG_UP_LEFT = 1 };
+
+/* gba_config.flags */
+#define GBA_FLAG_TIMING 1u    /* record HIP events around the DP-fill and traceback kernels */
+
+typedef struct gba_ctx gba_ctx;
+
+typedef struct {
+    int32_t device;        /* HIP device ordinal */
+    uint32_t flags;
+    void *stream;          /* hipStream_t to run on; NULL: the ctx creates its own */
+} gba_config;
+
+/*
+ * Scoring and band parameters: the hot-path subset of MappingParameters
+ * (iblasr/MappingParameters.h:207-381) plus the 5x5 SMRTDistanceMatrix as main()
+ * leaves it (Blasr.cpp:910-937).  Lower scores are better.
+ */
+typedef struct {
+    int32_t sub[5][5];          /* [query code][target code], codes A,C,G,T,N = 0..4 */
+    int32_t ins, del;           /* DP cost of a query base against a gap / a target base against a gap */
+    int32_t affine_open, affine_extend;
+    int32_t stats_ins, stats_del;                     /* rescoring scorer (indel, indel), BlasrUtilsImpl.hpp:633-634 */
+    int32_t stats_affine_open, stats_affine_extend;
+    int32_t band, max_band;     /* guidedAlignBandSize / bandSize; cap on the widened half-width */
+    int32_t mode;               /* GBA_MODE_* */
+    int32_t tie_break;          /* GBA_TIE_* */
+    int32_t kband_k;            /* GBA_MODE_KBAND: half-width of the diagonal band */
+    int32_t stats_affine;       /* nonzero: rescoring charges each gap run open + length*extend */
+} gba_scoring;
+
+/* one gap-free run of the alignment: the reference's blasr::Block (BlasrUtilsImpl.hpp:745-746) */
+typedef struct { uint32_t q_pos, t_pos, length; } gba_block;
+
+/*
+ * A batch of independent (query, target, guide) pairs, struct-of-arrays.  Pair p
+ * is q_arena[q_off[p] .. +q_len[p]), t_arena[t_off[p] .. +t_len[p]) (ASCII,
+ * already sliced as BlasrUtilsImpl.hpp:693-703 does) and the guide
+ * blocks[blk_off[p] .. +n_blk[p]) with coordinates relative to those slices.
+ * Pairs may share arena bytes (all candidates of a read view the same query).
+ * All pointers are host pointers for gba_submit and device pointers for
+ * gba_submit_device.
+ */
+typedef struct {
+    uint32_t n_pairs;
+    const uint8_t *q_arena; const uint64_t *q_off; const uint32_t *q_len;
+    const uint8_t *t_arena; const uint64_t *t_off; const uint32_t *t_len;
+    const gba_block *blocks; const uint64_t *blk_off; const uint32_t *n_blk;
+    uint64_t q_arena_bytes, t_arena_bytes, n_blocks_total;   /* extents of the three arenas */
+} gba_batch;
+
+/* what RefineAlignment copies back into the candidate (BlasrUtilsImpl.hpp:745-772) */
+typedef struct {
+    int32_t status;             /* GBA_PAIR_* */
+    int32_t dp_score;           /* optimum of the banded DP (the value GuidedAlign returns) */
+    int32_t score;              /* ComputeAlignmentStats rescoring of the path, :733-736 -> candidate.score */
+    uint32_t q_pos, t_pos;      /* refinedAlignment.qPos / tPos: start of the DP region in q / t */
+    uint32_t n_blk;
+    uint64_t blk_off;           /* first block of this pair in gba_results.blocks */
+    uint32_t n_match, n_mismatch, n_ins, n_del;
+    uint32_t rows, cols;        /* query / target bases inside the DP region */
+    uint64_t ncells;            /* refinedAlignment.nCells: sum over guide rows of tPre+tPost+1 */
+} gba_pair_result;
+
+typedef struct {
+    gba_pair_result *pairs;     /* n_pairs entries */
+    gba_block *blocks;          /* arena for all pairs' blocks, relative to (q_pos, t_pos) */
+    uint64_t blocks_capacity;   /* in blocks */
+    uint64_t blocks_needed;     /* out: total blocks of the batch */
+} gba_results;
+
+/* live measurements of the last waited batch (GBA_FLAG_TIMING) */
+typedef struct {
+    float fill_ms;              /* DP-fill kernels, HIP events on the ctx stream */
+    float traceback_ms;
+    float total_ms;             /* first kernel to last kernel of the batch */
+    uint32_t fill_launches;
+    uint64_t cells;             /* sum of ncells over pairs with status OK */
+    uint64_t rows;              /* DP rows of the batch */
+    uint64_t record_bytes;      /* traceback bytes the fill kernels wrote */
+} gba_timing;
+
+/* Replaces the per-thread `MappingBuffers mappingBuffers;` (Blasr.cpp:771): device
+ * scratch is owned by the ctx, grow-only, freed by gba_destroy. */
+int gba_create(gba_ctx **out, const gba_config *cfg);
+void gba_destroy(gba_ctx *ctx);
+
+/* Replaces building distScoreFn / distScoreFn2 and choosing kernel and band
+ * (BlasrUtilsImpl.hpp:630-646, :705-731). */
+int gba_set_scoring(gba_ctx *ctx, const gba_scoring *s);
+
+/* Replaces the RefineAlignments loop over candidates (BlasrUtilsImpl.hpp:911-914)
+ * for a whole batch.  gba_submit copies the host batch to the device and starts
+ * it; gba_wait blocks, copies results into out->pairs / out->blocks (host
+ * buffers) and returns GBA_OK or GBA_E_NOSPACE. */
+int gba_submit(gba_ctx *ctx, const gba_batch *host_batch);
+int gba_wait(gba_ctx *ctx, gba_results *out);
+
+/* Same, for callers whose batch and result buffers already live in device
+ * memory (all pointers in `dev_batch` and `dev_out` are device pointers).
+ * Returns when the batch has completed; out->blocks_needed is filled in. */
+int gba_submit_device(gba_ctx *ctx, const gba_batch *dev_batch, gba_results *dev_out);
+
+int gba_get_timing(gba_ctx *ctx, gba_timing *t);
+int gba_last_hip_error(gba_ctx *ctx);
+const char *gba_strerror(int code);
+int gba_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GBA_H */
