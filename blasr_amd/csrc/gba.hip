@@ -39,8 +39,12 @@ constexpr int32_t UNREACH = 0x20000000;      // unbiased words at or above this 
 constexpr int32_t BIASW = 128 << 5;          // per-row bias of the byte substitution table
 constexpr uint32_t MAX_ROWS = 65535;         // keeps biased words inside int32 (see gba_set_scoring)
 constexpr uint32_t MAX_COLS = 1u << 20;
-constexpr int NCLS = 4;                      // LDS-slot classes of the lane-per-pair fill kernel: 32, 64, 128, 256
-constexpr int PAD_SLOTS = 8;                 // a lane touches up to 7 slots past its row end (see k_fill_linear)
+// Classes of the lane-per-pair fill kernel: a pair's class is the smallest kernel template
+// (unroll depth = LDS row slots = 16 x record dwords per row) that holds its widest
+// "shift + width".  Each non-empty class is one launch.
+constexpr int NCLS = 4;
+__host__ __device__ constexpr uint32_t cls_slots(int c) { return 32u << c; }
+__host__ __device__ constexpr uint32_t cls_rw(int c) { return 2u << c; }   // record dwords per row
 
 struct Plan {                 // device -> host after k_scan2 / k_plan
     uint64_t total_rows, total_cols;
@@ -94,7 +98,9 @@ __device__ __forceinline__ uint32_t base_code(uint8_t c)
 
 __device__ __forceinline__ uint64_t align16(uint64_t x) { return (x + 15) & ~uint64_t(15); }
 __device__ __forceinline__ uint64_t qc_offset(const Dev &d, uint32_t p) { return align16(d.row_off[p] + 32ull * p); }
-__device__ __forceinline__ uint64_t tc_offset(const Dev &d, uint32_t p) { return align16(d.col_off[p] + 32ull * p); }
+__device__ __forceinline__ uint64_t tc_offset(const Dev &d, uint32_t p) { return align16(d.col_off[p] + 64ull * p); }
+// guide words of a pair start 16-byte aligned and are followed by at least 29 spare words
+__device__ __forceinline__ uint64_t guide_offset(const Dev &d, uint32_t p) { return (d.row_off[p] + 32ull * p + 3) & ~uint64_t(3); }
 
 // ---------------------------------------------------------------- k_meta
 // DP region of each pair.  Guided modes: from the first block's start to the last block's end
@@ -186,7 +192,8 @@ __global__ __launch_bounds__(1024) void k_scan2(Dev d)
 
 // ---------------------------------------------------------------- k_pack
 // qc[i] = code of the query base of DP row i (1..Q), tc[j] = code of the target base of DP
-// column j (1..T); index 0 and 16 bytes past the end hold N so window loads never leave the pair.
+// column j (1..T); index 0 and the bytes past the end (16 for q, 48 for t) hold N so block loads
+// never leave the pair.
 __global__ __launch_bounds__(256) void k_pack(Dev d)
 {
     const uint32_t p = blockIdx.x;
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256) void k_pack(Dev d)
     const uint8_t *t = d.t_arena + d.t_off[p] + d.tS[p];
     for (uint32_t i = threadIdx.x; i <= Q + 16; i += blockDim.x)
         qc[i] = (i >= 1 && i <= Q) ? (uint8_t)base_code(q[i - 1]) : (uint8_t)4;
-    for (uint32_t j = threadIdx.x; j <= T + 16; j += blockDim.x)
+    for (uint32_t j = threadIdx.x; j <= T + 48; j += blockDim.x)
         tc[j] = (j >= 1 && j <= T) ? (uint8_t)base_code(t[j - 1]) : (uint8_t)4;
 }
 
@@ -208,13 +215,15 @@ __global__ __launch_bounds__(256) void k_pack(Dev d)
 //   tPost = w, tPre = min(w, c - lo_{r-1})     (the band never reaches back past the previous row)
 // Inside a block c advances by one per row with w = band; between blocks the common part of the
 // gap is walked diagonally and leftover query bases repeat the column, with
-// w = min(max_band, band + |drift|).  Emits one u32 per row: width | (lo_r - lo_{r-1}) << 16.
+// w = min(max_band, band + |drift|).  Emits one u32 per row:
+//   width (13 bits) | code of the row's query base << 13 | (lo_r - lo_{r-1}) << 16.
 __global__ void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
 {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= d.n || d.status[p] != GBA_PAIR_OK) return;
     const uint32_t Q = d.Q[p], T = d.T[p], tS = d.tS[p];
-    uint32_t *g = d.guide + d.row_off[p];
+    uint32_t *g = d.guide + guide_offset(d, p);
+    const uint8_t *qc = d.qcodes + qc_offset(d, p);
     const int B = mode == GBA_MODE_KBAND ? kband_k : min(band, max_band);
     uint32_t W0 = min(T, (uint32_t)B) + 1;
     g[0] = W0;
@@ -263,8 +272,8 @@ __global__ void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
         const uint32_t W = hi - lo + 1, dl = lo - lo_prev;
         ncells += (uint64_t)tPre + w + 1;
         span = max(span, dl + W);
-        if (dl > 65535u || W > 65535u) wide = true;
-        g[r] = (W & 0xffffu) | (dl << 16);
+        if (dl > 65535u || W > 8191u) wide = true;
+        g[r] = (W & 0x1fffu) | ((uint32_t)qc[r] << 13) | (dl << 16);
         lo_prev = lo;
     }
     d.span[p] = span; d.ncells[p] = ncells; d.lo_last[p] = lo_prev;
@@ -285,7 +294,8 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d)
         uint32_t c = NCLS;
         if (d.status[p] == GBA_PAIR_OK) {
             const uint32_t s = d.span[p];
-            c = s <= 32 ? 0 : s <= 64 ? 1 : s <= 128 ? 2 : s <= 256 ? 3 : NCLS;
+            c = NCLS;
+            for (int k = NCLS - 1; k >= 0; k--) if (s <= cls_slots(k)) c = (uint32_t)k;
             if (c == NCLS) d.status[p] = GBA_PAIR_TOO_WIDE;
             else atomicAdd(&cnt[c], 1u);
         }
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d)
             if (threadIdx.x == 0) run[k] += (uint32_t)tot;
             __syncthreads();
         }
-        const uint64_t rd = c < NCLS ? (uint64_t)d.rows[p] * (2u << c) : 0;
+        const uint64_t rd = c < NCLS ? (uint64_t)d.rows[p] * cls_rw((int)c) : 0;
         uint64_t e = block_excl_scan(rd, sm, &tot);
         if (p < d.n) d.rec_off[p] = carry + e;
         carry += tot;
@@ -374,13 +384,23 @@ struct CellGroups {
     }
 };
 
+// Memory traffic is kept off the per-row critical path: guide words and target codes arrive in
+// chunks (CH rows / 32 columns at a time), are requested one chunk ahead into registers and
+// installed into small LDS rings at chunk boundaries, so the only vector-memory wait sits at a
+// boundary and covers loads issued a whole chunk earlier.  Record rows are stored directly and
+// never waited for.
+constexpr int CH = 8;                         // rows per guide chunk
+constexpr int LDS_TAB = 16, LDS_GBUF = 2 * CH * 64, LDS_TBUF = 16 * 64;
+
 template <int KMAX>
-__global__ __launch_bounds__(64) void k_fill_linear(Dev d, FillConst fc, uint32_t cls)
+__global__ __launch_bounds__(64) void k_fill_linear(Dev d, FillConst fc, uint32_t cls, uint32_t slots)
 {
     extern __shared__ uint32_t lds[];
     constexpr int RW = KMAX / 16;
     const int lane = threadIdx.x;
-    uint32_t *tab = lds + (KMAX + PAD_SLOTS) * 64;
+    uint32_t *tab = lds + (slots + PAD_SLOTS) * 64;
+    uint32_t *gbuf = tab + LDS_TAB;           // [2*CH rows][lane]: guide words of chunks c, c+1
+    uint32_t *tbuf = gbuf + LDS_GBUF;         // [2 blocks][8 dwords][lane]: target codes, 32 columns per block
     if (lane < 10) tab[lane] = fc.mrow[lane];
     __syncthreads();
     const uint32_t cnt = d.plan->cls_count[cls], cbase = d.plan->cls_base[cls];
@@ -389,54 +409,104 @@ __global__ __launch_bounds__(64) void k_fill_linear(Dev d, FillConst fc, uint32_
     const bool live = idx < cnt;
     const uint32_t p = d.order[cbase + (live ? idx : cnt - 1)];
     const uint32_t Q = live ? d.Q[p] : 0, T = d.T[p];
-    const uint32_t *g = d.guide + d.row_off[p];
+    const uint32_t *g = d.guide + guide_offset(d, p);
     uint32_t *rec = d.rec + d.rec_off[p];
-    const uint8_t *qc = d.qcodes + qc_offset(d, p);
     const uint8_t *tc = d.tcodes + tc_offset(d, p);
 
     uint32_t maxQ = Q;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) maxQ = max(maxQ, (uint32_t)__shfl_xor((int)maxQ, o, 64));
 
-    // target-code window: two dwords = columns [tb, tb+8), next two prefetched
-    uint32_t tb = 0, tw0, tw1, tn0, tn1;
-    { const uint2 a = *(const uint2 *)(tc), b = *(const uint2 *)(tc + 8); tw0 = a.x; tw1 = a.y; tn0 = b.x; tn1 = b.y; }
+    // ---- target-code blocks: the ring holds blocks tblk-1 and tblk, tp* is block tblk+1 in flight
+    auto tblock_ok = [&](uint32_t b) { return 32u * b <= T + 17u; };   // k_pack pads 48 codes past T
+    uint32_t tblk = 1;
+    uint4 tpa = make_uint4(0, 0, 0, 0), tpb = tpa;
+    {
+        const uint4 a = *(const uint4 *)(tc), b = *(const uint4 *)(tc + 16);
+        uint4 c4 = tpa, d4 = tpa;
+        if (tblock_ok(1)) { c4 = *(const uint4 *)(tc + 32); d4 = *(const uint4 *)(tc + 48); }
+        if (tblock_ok(2)) { tpa = *(const uint4 *)(tc + 64); tpb = *(const uint4 *)(tc + 80); }
+        uint32_t *t0 = tbuf + lane, *t1 = tbuf + 8 * 64 + lane;
+        t0[0] = a.x; t0[64] = a.y; t0[128] = a.z; t0[192] = a.w; t0[256] = b.x; t0[320] = b.y; t0[384] = b.z; t0[448] = b.w;
+        t1[0] = c4.x; t1[64] = c4.y; t1[128] = c4.z; t1[192] = c4.w; t1[256] = d4.x; t1[320] = d4.y; t1[384] = d4.z; t1[448] = d4.w;
+    }
     auto tcode = [&](uint32_t c) -> uint32_t {
-        if (c - tb >= 8u) {
-            if (c - tb < 16u) { tw0 = tn0; tw1 = tn1; tb += 8; }
-            else { tb = c & ~7u; const uint2 a = *(const uint2 *)(tc + tb); tw0 = a.x; tw1 = a.y; }
-            const uint2 b = *(const uint2 *)(tc + tb + 8);
-            tn0 = b.x; tn1 = b.y;
-        }
-        const uint32_t wsel = (c & 4u) ? tw1 : tw0;
-        return (wsel >> ((c & 3u) * 8u)) & 7u;
+        const uint32_t b = c >> 5;
+        if (b + 1u - tblk <= 1u)        // b == tblk-1 or b == tblk
+            return ((const uint8_t *)tbuf)[(((b & 1u) * 8u + ((c & 31u) >> 2)) * 64u + lane) * 4u + (c & 3u)];
+        return tc[c];                   // outside the ring (long jump or re-entry): direct load
     };
 
-    // row 0: cell j costs j deletions, arrows Left
-    uint32_t Wp = live ? (g[0] & 0xffffu) : 0, lo = 0;
+    // ---- guide chunks: LDS ring holds chunks c and c+1, gp* is chunk c+2 in flight
+    uint4 gpa = make_uint4(0, 0, 0, 0), gpb = gpa;
+    {
+        uint4 a = gpa, b = gpa, c4 = gpa, d4 = gpa;
+        if (live) { a = *(const uint4 *)(g); b = *(const uint4 *)(g + 4); }
+        if (live && CH <= Q) { c4 = *(const uint4 *)(g + CH); d4 = *(const uint4 *)(g + CH + 4); }
+        if (live && 2 * CH <= Q) { gpa = *(const uint4 *)(g + 2 * CH); gpb = *(const uint4 *)(g + 2 * CH + 4); }
+        uint32_t *g0 = gbuf + lane, *g1 = gbuf + CH * 64 + lane;
+        g0[0] = a.x; g0[64] = a.y; g0[128] = a.z; g0[192] = a.w; g0[256] = b.x; g0[320] = b.y; g0[384] = b.z; g0[448] = b.w;
+        g1[0] = c4.x; g1[64] = c4.y; g1[128] = c4.z; g1[192] = c4.w; g1[256] = d4.x; g1[320] = d4.y; g1[384] = d4.z; g1[448] = d4.w;
+    }
+
+    // ---- row 0: cell j costs j deletions, arrows Left
+    uint32_t Wp = live ? (gbuf[lane] & 0x1fffu) : 0, lo = 0;
     for (uint32_t k = 0; __any(k < Wp); k++)
         if (k < Wp) lds[k * 64 + lane] = ((uint32_t)((int32_t)k * fc.del) << 5) | tcode(k);
     if (live) {
         const uint32_t allL = fc.codeL * 0x55555555u;
         for (int w = 0; w < RW; w++) rec[w] = allL;
     }
-
-    uint32_t gnext = (live && Q >= 1) ? g[1] : 0;
-    uint32_t qnext = qc[1];
     uint32_t final_word = INFW;
     if (live && Q == 0) final_word = lds[T * 64 + lane];
 
+    // two-row software pipeline over the guide ring: g1 = word of the next row, m* = matrix row of
+    // the current row
+    uint32_t g0w = gbuf[1 * 64 + lane];
+    uint32_t mlo = tab[((g0w >> 13) & 7u) * 2], mhi = tab[((g0w >> 13) & 7u) * 2 + 1];
+    uint32_t g1w = gbuf[2 * 64 + lane];
+
     for (uint32_t i = 1; i <= maxQ; i++) {
+        if ((i & (CH - 1)) == 0) {
+            // chunk boundary (uniform): chunk c = i/CH starts; install chunk c+1, request chunk c+2
+            const uint32_t c = i / CH;
+            uint32_t *gi = gbuf + ((c + 1) & 1u) * (CH * 64) + lane;
+            gi[0] = gpa.x; gi[64] = gpa.y; gi[128] = gpa.z; gi[192] = gpa.w;
+            gi[256] = gpb.x; gi[320] = gpb.y; gi[384] = gpb.z; gi[448] = gpb.w;
+            if (live && (c + 2) * CH <= Q) { gpa = *(const uint4 *)(g + (c + 2) * CH); gpb = *(const uint4 *)(g + (c + 2) * CH + 4); }
+            // target codes: once the lane's next new column lies in block tblk, block tblk-1 is dead
+            if (lo + Wp >= 32u * tblk) {
+                uint32_t *ti = tbuf + ((tblk + 1u) & 1u) * (8 * 64) + lane;
+                ti[0] = tpa.x; ti[64] = tpa.y; ti[128] = tpa.z; ti[192] = tpa.w;
+                ti[256] = tpb.x; ti[320] = tpb.y; ti[384] = tpb.z; ti[448] = tpb.w;
+                tblk++;
+                if (tblock_ok(tblk + 1u)) {
+                    tpa = *(const uint4 *)(tc + 32u * (tblk + 1u));
+                    tpb = *(const uint4 *)(tc + 32u * (tblk + 1u) + 16u);
+                }
+            }
+        }
         const bool act = i <= Q;
-        const uint32_t gcur = gnext, qcode = qnext;
-        if (i < Q) { gnext = g[i + 1]; qnext = qc[i + 1]; }
-        const uint32_t W = act ? (gcur & 0xffffu) : 0u, dsh = act ? (gcur >> 16) : 0u;
+        const uint32_t gcur = g0w, cmlo = mlo, cmhi = mhi;
+        // fetch for the next rows (results are consumed after this row's cells)
+        g0w = g1w;
+        mlo = tab[((g0w >> 13) & 7u) * 2]; mhi = tab[((g0w >> 13) & 7u) * 2 + 1];
+        g1w = gbuf[((i + 2) & (2 * CH - 1)) * 64 + lane];     // row i+2 is always inside chunks c, c+1
+
+        const uint32_t W = act ? (gcur & 0x1fffu) : 0u, dsh = act ? (gcur >> 16) : 0u;
         // columns entering on the right: previous-layout slots [Wp, dsh + W)
-        for (uint32_t s = Wp; __any(act && s < dsh + W); s++)
-            if (act && s < dsh + W) lds[s * 64 + lane] = INFW | tcode(lo + s);
+        {
+            const uint32_t send = act ? dsh + W : 0u;
+            for (uint32_t s = Wp; __any(s < send); s += 4) {
+                if (s < send) {
+                    const uint32_t c0 = tcode(lo + s), c1 = tcode(lo + s + 1), c2 = tcode(lo + s + 2), c3 = tcode(lo + s + 3);
+                    uint32_t *w4 = lds + s * 64 + lane;      // slots up to send+2 < KMAX + PAD_SLOTS
+                    w4[0] = INFW | c0; w4[64] = INFW | c1; w4[128] = INFW | c2; w4[192] = INFW | c3;
+                }
+            }
+        }
         uint32_t diag = INFW, left = INFW;
         if (act && dsh >= 1) diag = lds[(dsh - 1) * 64 + lane];
-        const uint32_t mlo = tab[qcode * 2], mhi = tab[qcode * 2 + 1];
         const uint32_t *rd = lds + dsh * 64 + lane;
         uint32_t *wr = lds + lane;
         uint32_t r[RW];
@@ -447,7 +517,7 @@ __global__ __launch_bounds__(64) void k_fill_linear(Dev d, FillConst fc, uint32_
         // reads of group g+1 touch slots above every slot group g writes).
         uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0;
         if (0 < W) { u0 = rd[0]; u1 = rd[64]; u2 = rd[128]; u3 = rd[192]; }
-        CellGroups<0, KMAX>::run(rd, wr, W, mlo, mhi, fc.cU, fc.cL, diag, left, u0, u1, u2, u3, r);
+        CellGroups<0, KMAX>::run(rd, wr, W, cmlo, cmhi, fc.cU, fc.cL, diag, left, u0, u1, u2, u3, r);
         if (act) {
             uint32_t *rr = rec + (uint64_t)i * RW;
             if constexpr (RW == 2) *(uint2 *)rr = make_uint2(r[0], r[1]);
@@ -482,10 +552,9 @@ __global__ __launch_bounds__(64) void k_traceback(Dev d, TbConst tc_, gba_pair_r
     gba_pair_result &R = res[p];
     if (d.status[p] != GBA_PAIR_OK) return;      // fill found the end cell unreachable
     const uint32_t Q = d.Q[p], T = d.T[p];
-    const uint32_t RW = 2u << d.cls[p];
+    const uint32_t RW = cls_rw((int)d.cls[p]);
     const uint32_t *rec = d.rec + d.rec_off[p];
-    const uint32_t *g = d.guide + d.row_off[p];
-    const uint8_t *qc = d.qcodes + qc_offset(d, p);
+    const uint32_t *g = d.guide + guide_offset(d, p);
     const uint8_t *tc = d.tcodes + tc_offset(d, p);
     gba_block *out = d.blk_scratch + d.row_off[p];
     const uint32_t cap = Q + 1;
@@ -498,11 +567,11 @@ __global__ __launch_bounds__(64) void k_traceback(Dev d, TbConst tc_, gba_pair_r
     int st = GBA_PAIR_OK;
     while (i > 0 || j > 0) {
         const uint32_t k = j - lo;
-        if (++steps > limit || k >= (gw & 0xffffu)) { st = GBA_PAIR_UNREACHABLE; break; }
+        if (++steps > limit || k >= (gw & 0x1fffu)) { st = GBA_PAIR_UNREACHABLE; break; }
         const uint32_t a = (rec[(uint64_t)i * RW + (k >> 4)] >> ((k & 15u) * 2u)) & 3u;
         if (a == 0) {
             if (i == 0 || j == 0) { st = GBA_PAIR_UNREACHABLE; break; }
-            const uint32_t qb = qc[i], tb = tc[j];
+            const uint32_t qb = (gw >> 13) & 7u, tb = tc[j];
             if (qb == tb) nM++; else nX++;
             score += sub[qb * 5 + tb];
             run++; i--; j--; lo -= gw >> 16; gw = g[i]; prev_op = 0;
@@ -582,6 +651,8 @@ struct Buf {
 
 }  // namespace
 
+constexpr int NAUX = 4;
+
 struct gba_ctx {
     int device = 0;
     uint32_t flags = 0;
@@ -603,6 +674,8 @@ struct gba_ctx {
     int flight_rc = 0;
     uint64_t flight_needed = 0;
     hipEvent_t ev[6] = {};
+    hipStream_t aux[4] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {};
     gba_timing timing = {};
 };
 
@@ -631,16 +704,17 @@ void release(Buf &b)
 }
 
 template <int KMAX>
-int launch_fill(gba_ctx *c, const Dev &d, uint32_t cls, uint32_t count)
+int launch_fill(gba_ctx *c, const Dev &d, uint32_t cls, uint32_t count, hipStream_t st)
 {
-    if (!count) return GBA_OK;
-    const size_t lds = ((size_t)(KMAX + PAD_SLOTS) * 64 + 16) * 4;
+    const uint32_t slots = cls_slots((int)cls);
+    const size_t lds = ((size_t)(slots + PAD_SLOTS) * 64 + LDS_TAB + LDS_GBUF + LDS_TBUF) * 4;
     static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_fill_linear<KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!attr_set) {
+        const size_t mx = ((size_t)(KMAX + PAD_SLOTS) * 64 + LDS_TAB + LDS_GBUF + LDS_TBUF) * 4;
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_fill_linear<KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_fill_linear<KMAX>, dim3((count + 63) / 64), dim3(64), lds, c->stream, d, c->fc, cls);
+    hipLaunchKernelGGL(k_fill_linear<KMAX>, dim3((count + 63) / 64), dim3(64), lds, st, d, c->fc, cls, slots);
     HIPCHK(c, hipGetLastError());
     return GBA_OK;
 }
@@ -684,9 +758,9 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     HIPCHK(c, hipMemcpyAsync(c->h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const uint64_t rows = c->h_plan->total_rows, cols = c->h_plan->total_cols;
-    { int rc = ensure(c, c->b_guide, (size_t)(rows + 4) * 4); if (rc) return rc; }
+    { int rc = ensure(c, c->b_guide, (size_t)(rows + 32ull * n + 64) * 4); if (rc) return rc; }
     { int rc = ensure(c, c->b_qc, (size_t)(rows + 32ull * n + 64)); if (rc) return rc; }
-    { int rc = ensure(c, c->b_tc, (size_t)(cols + 32ull * n + 64)); if (rc) return rc; }
+    { int rc = ensure(c, c->b_tc, (size_t)(cols + 64ull * n + 128)); if (rc) return rc; }
     { int rc = ensure(c, c->b_blk, (size_t)(rows + 4) * sizeof(gba_block)); if (rc) return rc; }
     d.guide = (uint32_t *)c->b_guide.ptr;
     d.qcodes = (uint8_t *)c->b_qc.ptr; d.tcodes = (uint8_t *)c->b_tc.ptr;
@@ -704,14 +778,31 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     gba_pair_result *res = out->pairs;
     hipLaunchKernelGGL(k_results_init, dim3(g256), dim3(256), 0, s, d, res);
     if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
+    // One launch per non-empty class, spread over auxiliary streams so that classes with few
+    // waves share the GPU instead of running back to back.
     uint32_t launches = 0;
     {
-        int rc;
-        if ((rc = launch_fill<32>(c, d, 0, pl.cls_count[0]))) return rc;
-        if ((rc = launch_fill<64>(c, d, 1, pl.cls_count[1]))) return rc;
-        if ((rc = launch_fill<128>(c, d, 2, pl.cls_count[2]))) return rc;
-        if ((rc = launch_fill<256>(c, d, 3, pl.cls_count[3]))) return rc;
-        for (int k = 0; k < NCLS; k++) launches += pl.cls_count[k] ? 1 : 0;
+        HIPCHK(c, hipEventRecord(c->ev_fork, s));
+        bool used[NAUX] = {};
+        for (int k = 0; k < NCLS; k++) {
+            const uint32_t cnt = pl.cls_count[k];
+            if (!cnt) continue;
+            const int a = (int)(launches % NAUX);
+            hipStream_t st = c->aux[a];
+            if (!used[a]) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0)); used[a] = true; }
+            int rc;
+            if (k == 0) rc = launch_fill<32>(c, d, 0, cnt, st);
+            else if (k == 1) rc = launch_fill<64>(c, d, 1, cnt, st);
+            else if (k == 2) rc = launch_fill<128>(c, d, 2, cnt, st);
+            else rc = launch_fill<256>(c, d, 3, cnt, st);
+            if (rc) return rc;
+            launches++;
+        }
+        for (int a = 0; a < NAUX; a++) {
+            if (!used[a]) continue;
+            HIPCHK(c, hipEventRecord(c->ev_join[a], c->aux[a]));
+            HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[a], 0));
+        }
     }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (pl.n_ok)
@@ -779,6 +870,12 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
         if (hipHostMalloc((void **)&c->h_plan, sizeof(Plan)) != hipSuccess) { rc = GBA_E_NOMEM; break; }
         if (hipHostMalloc((void **)&c->h_needed, 8) != hipSuccess) { rc = GBA_E_NOMEM; break; }
         for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rc = GBA_E_HIP; break; }
+        if (rc) break;
+        if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { rc = GBA_E_HIP; break; }
+        for (int a = 0; a < NAUX; a++) {
+            if (hipStreamCreateWithFlags(&c->aux[a], hipStreamNonBlocking) != hipSuccess) { rc = GBA_E_HIP; break; }
+            if (hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming) != hipSuccess) { rc = GBA_E_HIP; break; }
+        }
     } while (0);
     if (rc) { gba_destroy(c); return rc; }
     *out = c;
@@ -799,6 +896,11 @@ void gba_destroy(gba_ctx *c)
     if (c->h_plan) (void)hipHostFree(c->h_plan);
     if (c->h_needed) (void)hipHostFree(c->h_needed);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int a = 0; a < NAUX; a++) {
+        if (c->ev_join[a]) (void)hipEventDestroy(c->ev_join[a]);
+        if (c->aux[a]) { (void)hipStreamSynchronize(c->aux[a]); (void)hipStreamDestroy(c->aux[a]); }
+    }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
