@@ -43,6 +43,7 @@ constexpr uint32_t MAX_COLS = 1u << 20;
 // (unroll depth = LDS row slots = 16 x record dwords per row) that holds its widest
 // "shift + width".  Each non-empty class is one launch.
 constexpr int NCLS = 4;
+constexpr int PAD_SLOTS = 8;                 // a lane touches up to 7 slots past its row end (see k_fill_linear)
 __host__ __device__ constexpr uint32_t cls_slots(int c) { return 32u << c; }
 __host__ __device__ constexpr uint32_t cls_rw(int c) { return 2u << c; }   // record dwords per row
 
