@@ -77,6 +77,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libgba.so not built: run `python -m blasr_amd.build` (hipcc, gfx950)")
+        # One HIP runtime per process: PyTorch ships its own libamdhip64; importing it first makes
+        # libgba.so bind to that copy, so tensors and gba contexts share one runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name in EXPORTS:
             getattr(L, name)          # AttributeError if a declared symbol is not exported

@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void k_pack(Dev d)
 // ---------------------------------------------------------------- k_guide
 // Guide rows in DP coordinates: row r covers columns [lo_r, hi_r], 0 <= lo_r <= hi_r <= T, row 0
 // is the boundary row.  A row has a centre column c and a half-width w:
-//   tPost = w, tPre = min(w, c - lo_{r-1})     (the band never reaches back past the previous row)
+//   tPost = w, tPre = min(w, c - lo_{r-1})     (the band never reaches back past the previous row;
+//   on the first row of a block w is replaced by max_band here, so target-only gaps stay connected)
 // Inside a block c advances by one per row with w = band; between blocks the common part of the
 // gap is walked diagonally and leftover query bases repeat the column, with
 // w = min(max_band, band + |drift|).  Emits one u32 per row:
@@ -241,6 +242,7 @@ __global__ void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
         remaining = blen; c = bt - tS; step = 1;    // c is pre-incremented below: first row centre = bt - tS + 1
     }
     uint32_t ins_left = 0, wgap = 0;
+    bool first = mode != GBA_MODE_KBAND;      // first row of a block: reaches back to the previous row's first column
     for (uint32_t r = 1; r <= Q; r++) {
         if (mode != GBA_MODE_KBAND) {
             while (remaining == 0) {
@@ -258,7 +260,7 @@ __global__ void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
                 } else if (phase == 1) {
                     phase = 2; remaining = ins_left; w = wgap; step = 0;
                 } else {
-                    phase = 0; remaining = blen; w = (uint32_t)B; step = 1;
+                    phase = 0; remaining = blen; w = (uint32_t)B; step = 1; first = true;
                     c = bt - tS;                 // jump: the next row's centre is the block's first column
                 }
             }
@@ -267,7 +269,7 @@ __global__ void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
             step = 1;
         }
         c += step;
-        const uint32_t tPre = min(w, c - lo_prev);
+        const uint32_t tPre = min(first ? max((uint32_t)max_band, w) : w, c - lo_prev);
         const uint32_t lo = c - tPre;
         const uint32_t hi = min(T, c + w);
         const uint32_t W = hi - lo + 1, dl = lo - lo_prev;
@@ -275,7 +277,7 @@ __global__ void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
         span = max(span, dl + W);
         if (dl > 65535u || W > 8191u) wide = true;
         g[r] = (W & 0x1fffu) | ((uint32_t)qc[r] << 13) | (dl << 16);
-        lo_prev = lo;
+        lo_prev = lo; first = false;
     }
     d.span[p] = span; d.ncells[p] = ncells; d.lo_last[p] = lo_prev;
     if (wide) d.status[p] = GBA_PAIR_TOO_WIDE;

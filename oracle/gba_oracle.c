@@ -108,20 +108,22 @@ static int check_blocks(const gbo_block *b, int nb, uint32_t q_len, uint32_t t_l
     return GBO_OK;
 }
 
-static void add_row(guide_row *g, int gi, int q, int t, int w)
+static void add_row(guide_row *g, int gi, int q, int t, int w, int back)
 {
     const guide_row *p = &g[gi - 1];
     int prevLo = p->t - p->tPre;
     g[gi].q = q;
     g[gi].t = t;
     g[gi].tPost = w;
-    /* the band never reaches further back than the previous row's first column */
-    g[gi].tPre = imin(w, t - prevLo);
+    /* the band never reaches further back than the previous row's first column; `back` is
+     * how far back it may reach at most (w, except on the first row of a block) */
+    g[gi].tPre = imin(back, t - prevLo);
 }
 
 /* AlignmentToGuide: one row per query base from the first block's start to the
  * last block's end, plus the boundary row.  Inside a block the centre advances
- * one target base per row with half-width `band`; between two blocks the common
+ * one target base per row with half-width `band` (the block's first row reaches
+ * back to the previous row's first column); between two blocks the common
  * part of the gap is walked diagonally and any remaining query bases repeat the
  * last target column, with half-width band + |drift| (capped at max_band). */
 static guide_row *build_guide(const gbo_block *b, int nb, const gbo_params *P, int *n_rows)
@@ -135,16 +137,18 @@ static guide_row *build_guide(const gbo_block *b, int nb, const gbo_params *P, i
     g[0].q = qStart - 1; g[0].t = tStart - 1; g[0].tPre = 0; g[0].tPost = B;
     int gi = 1;
     for (int i = 0; i < nb; i++) {
+        /* the first row of a block reaches back to the previous row's first column (capped at
+         * max_band), so that a target-only gap, which adds no rows of its own, stays connected */
         for (uint32_t p = 0; p < b[i].length; p++)
-            add_row(g, gi++, (int)(b[i].q_pos + p), (int)(b[i].t_pos + p), B);
+            add_row(g, gi++, (int)(b[i].q_pos + p), (int)(b[i].t_pos + p), B, p == 0 ? P->max_band : B);
         if (i + 1 < nb) {
             int q = (int)(b[i].q_pos + b[i].length), t = (int)(b[i].t_pos + b[i].length);
             int qGap = (int)b[i + 1].q_pos - q, tGap = (int)b[i + 1].t_pos - t;
             int drift = tGap - qGap;
             int w = imin(P->max_band, P->band + iabs(drift));
             int diag = imin(qGap, tGap);
-            for (int x = 0; x < diag; x++) add_row(g, gi++, q++, t++, w);
-            while (q < (int)b[i + 1].q_pos) add_row(g, gi++, q++, t - 1, w);
+            for (int x = 0; x < diag; x++) add_row(g, gi++, q++, t++, w, w);
+            while (q < (int)b[i + 1].q_pos) add_row(g, gi++, q++, t - 1, w, w);
         }
     }
     *n_rows = gi;   /* == Q + 1 */

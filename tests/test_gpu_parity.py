@@ -1,0 +1,228 @@
+"""GPU parity tests: everything goes through the C-ABI (libgba.so) and is compared bit for bit
+with the CPU oracle.  Parity with the BLASR binary itself is unpinned (see oracle/gba_oracle.c)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def api():
+    from blasr_amd import api as a
+    return a
+
+
+@pytest.fixture(scope="module")
+def ctx(api):
+    c = api.Context(0, timing=True)
+    yield c
+    c.close()
+
+
+def _run(ctx, api, oracle, batch, expect_status=None, **kw):
+    ctx.set_scoring(api.make_scoring(**kw))
+    pairs, blocks, rc = ctx.refine_host(batch)
+    assert rc == 0
+    util.compare_batch(oracle, batch, oracle.make_params(**kw), pairs, blocks, expect_status)
+    return pairs, blocks
+
+
+@pytest.mark.parametrize("fixture", ["micro.json", "synthetic_small.json"])
+def test_golden_fixtures(ctx, api, oracle, fixture):
+    cases = json.load(open(os.path.join(GOLD, fixture)))["cases"]
+    by_params = {}
+    for c in cases:
+        by_params.setdefault(json.dumps(c["params"], sort_keys=True), []).append(c)
+    for pj, cs in by_params.items():
+        kw = json.loads(pj)
+        batch = util.make_batch([(c["q"], c["t"], c["blocks"]) for c in cs])
+        ctx.set_scoring(api.make_scoring(**kw))
+        pairs, blocks, rc = ctx.refine_host(batch)
+        assert rc == 0
+        for c, k in zip(cs, pairs):
+            e = c["expect"]["result"]
+            assert int(k["status"]) == e["status"], c["name"]
+            if e["status"] != 0:
+                continue
+            for f in util.FIELDS:
+                assert int(k[f]) == e[f], (c["name"], f)
+            kb = blocks[int(k["blk_off"]):int(k["blk_off"]) + int(k["n_blk"])]
+            assert [[int(b["q_pos"]), int(b["t_pos"]), int(b["length"])] for b in kb] == c["expect"]["blocks"], c["name"]
+
+
+def test_c1_plumbing(ctx, api, oracle, synth):
+    batch, cfg = synth.preset("c1_ecoli_plumbing", 300)
+    _run(ctx, api, oracle, batch)
+
+
+def test_c2_10kb(ctx, api, oracle, synth):
+    batch, cfg = synth.preset("c2_10kb_linear", 192)
+    pairs, _ = _run(ctx, api, oracle, batch)
+    assert int((pairs["status"] == 0).sum()) == 192
+
+
+def test_c4_decoys_and_n_runs(ctx, api, oracle, synth):
+    ref = synth.reference(3_000_000, seed=9, n_frac=0.02, n_run=1000)
+    batch = synth.generate(200, read_len=4000, seed=4000, decoy_every=10, ref=ref)
+    _run(ctx, api, oracle, batch)
+
+
+def test_wide_band(ctx, api, oracle, synth):
+    batch = synth.generate(24, read_len=3000, p_ins=0.11, p_del=0.06, p_sub=0.03, seed=5000)
+    _run(ctx, api, oracle, batch, band=40)
+    _run(ctx, api, oracle, batch, band=100)
+
+
+@pytest.mark.parametrize("kw", [dict(tie_break=1), dict(n_score=3), dict(band=0), dict(band=3),
+                                dict(ins=2, dele=7, indel=3), dict(match=-1, mismatch=1, ins=1, dele=1, indel=1),
+                                dict(stats_affine=1, stats_affine_open=4, stats_affine_extend=1),
+                                dict(max_band=12)])
+def test_parameter_variants(ctx, api, oracle, synth, kw):
+    batch = synth.generate(64, read_len=1500, len_jitter=800, seed=31)
+    _run(ctx, api, oracle, batch, **kw)
+
+
+def test_custom_matrix(ctx, api, oracle, synth):
+    rng = np.random.default_rng(7)
+    sub = rng.integers(-9, 12, size=(5, 5))
+    np.fill_diagonal(sub, -6)
+    batch = synth.generate(48, read_len=1200, seed=32)
+    _run(ctx, api, oracle, batch, sub=sub.tolist())
+
+
+def test_edge_cases_in_one_batch(ctx, api, oracle):
+    q = "ACGTTGCAAGGCTTAACCGGTTACGATCGATCGGCTA"
+    pairs_list = [
+        (q, q, [(0, 0, len(q))]),                               # perfect
+        (q, q, []),                                             # empty guide: passed through
+        (q, q, [(0, 0, len(q) + 1)]),                           # block past the end
+        (q, q, [(0, 0, 10), (5, 12, 5)]),                       # overlapping blocks
+        (q.lower(), q, [(0, 0, 12), (20, 20, 10)]),             # lower case query
+        ("ACGTNNNNACGTACGT", "ACGTACGTACGTACGT", [(0, 0, 4), (8, 8, 8)]),   # N bases
+        ("A", "A", [(0, 0, 1)]),                                # smallest possible pair
+        (q, q + "TTTTTTTT", [(3, 5, 11)]),                      # guide not starting at 0, target longer
+        ("ACGTACGTAC" + "GGCCTTAACC", "ACGTACGTAC" + "T" * 30 + "GGCCTTAACC", [(0, 0, 10), (10, 40, 10)]),
+        ("ACGTACGTAC" + "G" * 25 + "GGCCTTAACC", "ACGTACGTAC" + "GGCCTTAACC", [(0, 0, 10), (35, 10, 10)]),
+    ]
+    batch = util.make_batch(pairs_list)
+    expect = [0, 1, 2, 2, 0, 0, 0, 0, 0, 0]
+    pairs, blocks = _run(ctx, api, oracle, batch, expect_status=expect)
+    assert int(pairs[1]["n_blk"]) == 0 and int(pairs[7]["q_pos"]) == 3 and int(pairs[7]["t_pos"]) == 5
+
+
+def test_shared_query_arena(ctx, api, oracle, synth):
+    """All candidates of a read view the same query bytes (BlasrUtilsImpl.hpp:700-703)."""
+    base = synth.generate(6, read_len=800, seed=50)
+    n = 6
+    q_off = np.repeat(base["q_off"][:1], n)             # every pair views read 0 ...
+    q_len = np.repeat(base["q_len"][:1], n)
+    b = dict(base)
+    b["q_off"], b["q_len"] = q_off, q_len
+    # ... against its own window, with a sparse guide that fits both
+    blocks, blk_off, n_blk = [], [], []
+    for i in range(n):
+        L = int(min(q_len[i], base["t_len"][i]))
+        blk_off.append(len(blocks)); n_blk.append(2)
+        blocks += [(0, 0, 11), (L - 11, L - 11, 11)]
+    arr = np.zeros(len(blocks), dtype=synth.BLOCK_DT)
+    for i, x in enumerate(blocks):
+        arr[i] = x
+    b["blocks"], b["blk_off"], b["n_blk"] = arr, np.array(blk_off, np.uint64), np.array(n_blk, np.uint32)
+    _run(ctx, api, oracle, b, band=30)
+
+
+def test_kband_global(ctx, api, oracle, synth):
+    base = synth.generate(40, read_len=700, len_jitter=300, seed=60)
+    base["n_blk"][:] = 0                                   # k-band ignores the guide
+    from blasr_amd import _lib
+    _run(ctx, api, oracle, base, mode=_lib.MODE_KBAND, kband_k=60)
+    pairs, _ = _run(ctx, api, oracle, base, mode=_lib.MODE_KBAND, kband_k=8)
+    assert (pairs["status"] == _lib.PAIR_END_OUT_OF_BAND).any()
+
+
+def test_device_path_equals_host_path(ctx, api, oracle, synth):
+    import torch
+    from blasr_amd import _lib
+    batch = synth.generate(256, read_len=2000, len_jitter=1000, seed=70)
+    ctx.set_scoring(api.make_scoring())
+    hp, hb, rc = ctx.refine_host(batch)
+    d = api.to_device(batch)
+    n = 256
+    out_pairs = torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0")
+    cap = int(ctx.blocks_needed)
+    out_blocks = torch.zeros((cap, 3), dtype=torch.int32, device="cuda:0")
+    rc, needed = ctx.refine_device(d, out_pairs, out_blocks)
+    assert rc == 0 and needed == cap
+    dp = out_pairs.cpu().numpy().view(_lib.PAIR_RESULT_DT)
+    db = out_blocks.cpu().numpy().view(np.uint32)
+    assert np.array_equal(dp, hp)
+    assert np.array_equal(db[:, 0], hb["q_pos"]) and np.array_equal(db[:, 1], hb["t_pos"]) and np.array_equal(db[:, 2], hb["length"])
+    tm = ctx.timing()
+    assert tm["cells"] == int(hp["ncells"].sum()) and tm["fill_ms"] > 0
+    # too small an arena: GBA_E_NOSPACE, the needed size is reported, leading pairs still fit
+    small = torch.zeros((cap // 2, 3), dtype=torch.int32, device="cuda:0")
+    rc, needed = ctx.refine_device(d, out_pairs, small)
+    assert rc == _lib.E_NOSPACE and needed == cap
+    dp2 = out_pairs.cpu().numpy().view(_lib.PAIR_RESULT_DT)
+    assert (dp2["status"] == _lib.PAIR_NOSPACE).any() and dp2["status"][0] == 0
+
+
+def test_host_nospace_and_reuse(ctx, api, oracle, synth):
+    from blasr_amd import _lib
+    ctx.set_scoring(api.make_scoring())
+    big = synth.generate(128, read_len=3000, seed=80)
+    small = synth.generate(16, read_len=500, seed=81)
+    p1, b1, rc = ctx.refine_host(big)
+    p2, b2, rc = ctx.refine_host(small)                  # scratch is reused by a smaller batch
+    util.compare_batch(oracle, small, oracle.make_params(), p2, b2)
+    p3, b3, rc = ctx.refine_host(big, blocks_capacity=100)
+    assert rc == _lib.E_NOSPACE and ctx.blocks_needed == len(b1)
+    assert (p3["status"] == _lib.PAIR_NOSPACE).sum() > 100
+
+
+def test_unsupported_scoring_is_refused(ctx, api):
+    from blasr_amd import _lib
+    with pytest.raises(_lib.GbaError):
+        ctx.set_scoring(api.make_scoring(mismatch=500))
+    ctx.set_scoring(api.make_scoring())
+
+
+def test_full_size_properties(ctx, api, oracle, synth):
+    """Benchmark-sized pairs: size-independent invariants on all pairs, oracle parity on a sample."""
+    batch, cfg = synth.preset("c2_10kb_linear", 2048)
+    ctx.set_scoring(api.make_scoring())
+    pairs, blocks, rc = ctx.refine_host(batch)
+    assert rc == 0 and (pairs["status"] == 0).all()
+    assert np.array_equal(pairs["n_match"] + pairs["n_mismatch"] + pairs["n_ins"], pairs["rows"])
+    assert np.array_equal(pairs["n_match"] + pairs["n_mismatch"] + pairs["n_del"], pairs["cols"])
+    assert np.array_equal(pairs["rows"], batch["q_len"]) and np.array_equal(pairs["cols"], batch["t_len"])
+    off = pairs["blk_off"].astype(np.int64)
+    assert np.array_equal(off[1:], np.cumsum(pairs["n_blk"].astype(np.int64))[:-1])
+    # blocks of every pair: increasing, inside the pair, lengths add up to the aligned columns
+    for p in range(0, 2048, 37):
+        b = blocks[off[p]:off[p] + int(pairs["n_blk"][p])]
+        qe = b["q_pos"].astype(np.int64) + b["length"]
+        te = b["t_pos"].astype(np.int64) + b["length"]
+        assert np.all(b["q_pos"][1:] >= qe[:-1]) and np.all(b["t_pos"][1:] >= te[:-1])
+        assert int(b["length"].sum()) == int(pairs["n_match"][p] + pairs["n_mismatch"][p])
+        # rescoring the path on the host reproduces the reported score
+        q, t, _ = synth.pair(batch, p)
+        sc = 0
+        for x in b:
+            qs = q[x["q_pos"]:x["q_pos"] + x["length"]]
+            ts = t[x["t_pos"]:x["t_pos"] + x["length"]]
+            eq = int((qs == ts).sum())
+            sc += -5 * eq + 6 * (len(qs) - eq)
+        sc += 5 * int(pairs["n_ins"][p] + pairs["n_del"][p])
+        assert sc == int(pairs["score"][p])
+    sample = {k: v for k, v in batch.items()}
+    ores, oblk = oracle.align_batch(sample, oracle.make_params(), 0, 24)
+    for p in range(24):
+        for f in util.FIELDS:
+            assert int(ores[p][f]) == int(pairs[p][f]), (f, p)
