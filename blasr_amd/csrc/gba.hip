@@ -39,16 +39,22 @@ constexpr int32_t UNREACH = 0x20000000;      // unbiased words at or above this 
 constexpr int32_t BIASW = 128 << 5;          // per-row bias of the byte substitution table
 constexpr uint32_t MAX_ROWS = 65535;         // keeps biased words inside int32 (see gba_set_scoring)
 constexpr uint32_t MAX_COLS = 1u << 20;
-// Classes of the lane-per-pair fill kernel: a pair's class is the smallest kernel template
-// (unroll depth = LDS row slots = 16 x record dwords per row) that holds its widest
-// "shift + width".  Each non-empty class is one launch.
+// Classes of the lane-per-pair fill kernel: a pair's class is the smallest LDS row buffer
+// (32 << class slots) that holds its widest "shift + width".  Each non-empty class is one launch.
 constexpr int NCLS = 4;
-constexpr int PAD_SLOTS = 8;                 // a lane touches up to 7 slots past its row end (see k_fill_linear)
+constexpr int PAD_SLOTS = 4;                 // a lane runs up to 3 cells past its row end (see k_fill)
+constexpr int CAP = 16;                      // cells per lane per step of k_fill
 __host__ __device__ constexpr uint32_t cls_slots(int c) { return 32u << c; }
-__host__ __device__ constexpr uint32_t cls_rw(int c) { return 2u << c; }   // record dwords per row
+__host__ __device__ constexpr uint32_t cls_rs(int c) { return 1u + (2u << c); }   // record dwords per row: meta + arrows
 
-struct Plan {                 // device -> host after k_scan2 / k_plan
-    uint64_t total_rows, total_cols;
+// Guide stream words (one stream per pair, built by k_guide, consumed by k_fill):
+//   ROW  width[0:10) | query base code[10:13) | shift of the first column[13:23) | codes of the
+//        first three columns entering the band on the right[23:32)
+//   EXT  eight more entering-column codes, 3 bits each; a row has ceil((entering - 3) / 8) of them
+constexpr uint32_t ROW_W_MASK = 1023u, ROW_META_MASK = 0x7fffffu;
+
+struct Plan {                 // device -> host after k_scan3 / k_plan
+    uint64_t total_rows, total_cols, total_words;
     uint64_t total_rec_dwords;
     uint64_t total_cells;
     uint32_t cls_count[NCLS + 1];
@@ -66,14 +72,14 @@ struct Dev {                  // per-batch device state, SoA per pair
     const gba_block *blocks;
     // per pair
     int32_t *status;
-    uint32_t *qS, *tS, *Q, *T, *rows, *cols, *span, *lo_last, *cls, *order;
-    uint64_t *row_off, *col_off, *rec_off, *ncells;
+    uint32_t *qS, *tS, *Q, *T, *rows, *cols, *wcap, *span, *lo_last, *cls, *order;
+    uint64_t *row_off, *col_off, *word_off, *rec_off, *ncells;
     int32_t *dp_score;
     Plan *plan;
     // arenas
-    uint32_t *guide;          // one u32 per DP row: width | shift << 16
+    uint32_t *stream;         // guide stream words
     uint8_t *qcodes, *tcodes;
-    uint32_t *rec;            // traceback records
+    uint32_t *rec;            // traceback records: per DP row one meta dword + 2-bit arrows
     gba_block *blk_scratch;
 };
 
@@ -81,7 +87,6 @@ struct FillConst {
     uint32_t mrow[10];        // per query code: 8 bytes = biased substitution costs against target codes 0..7
     int32_t cU, cL;           // (cost << 5) + (arrow code << 3) [+ BIASW for the vertical move]
     int32_t del;
-    uint32_t codeL;           // arrow code of the Left move (row 0 records)
 };
 
 struct TbConst {
@@ -98,29 +103,30 @@ __device__ __forceinline__ uint32_t base_code(uint8_t c)
 }
 
 __device__ __forceinline__ uint64_t align16(uint64_t x) { return (x + 15) & ~uint64_t(15); }
+// code arrays of a pair start 16-byte aligned and are followed by at least 17 spare bytes
 __device__ __forceinline__ uint64_t qc_offset(const Dev &d, uint32_t p) { return align16(d.row_off[p] + 32ull * p); }
-__device__ __forceinline__ uint64_t tc_offset(const Dev &d, uint32_t p) { return align16(d.col_off[p] + 64ull * p); }
-// guide words of a pair start 16-byte aligned and are followed by at least 29 spare words
-__device__ __forceinline__ uint64_t guide_offset(const Dev &d, uint32_t p) { return (d.row_off[p] + 32ull * p + 3) & ~uint64_t(3); }
+__device__ __forceinline__ uint64_t tc_offset(const Dev &d, uint32_t p) { return align16(d.col_off[p] + 32ull * p); }
 
 // ---------------------------------------------------------------- k_meta
 // DP region of each pair.  Guided modes: from the first block's start to the last block's end
 // (AlignmentToGuide: tStart/qStart = first block, tEnd/qEnd = last block end).  k-band: the
-// whole q x t rectangle.
+// whole q x t rectangle.  Also an upper bound on the pair's guide stream length.
 __global__ void k_meta(Dev d, int mode, int kband_k)
 {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= d.n) return;
     int st = GBA_PAIR_OK;
     uint32_t qS = 0, tS = 0, Q = 0, T = 0;
+    uint64_t drift_sum = 0;
     const uint32_t ql = d.q_len[p], tl = d.t_len[p];
+    uint32_t nb = 0;
     if (mode == GBA_MODE_KBAND) {
         Q = ql; T = tl;
         int64_t dd = (int64_t)tl - (int64_t)ql;
         if (dd < 0) dd = -dd;
         if (dd > kband_k) st = GBA_PAIR_END_OUT_OF_BAND;
     } else {
-        const uint32_t nb = d.n_blk[p];
+        nb = d.n_blk[p];
         if (nb == 0) st = GBA_PAIR_EMPTY_GUIDE;
         else {
             const gba_block *bl = d.blocks + d.blk_off[p];
@@ -130,6 +136,10 @@ __global__ void k_meta(Dev d, int mode, int kband_k)
                 if (len == 0 || (uint64_t)bq + len > ql || (uint64_t)bt + len > tl) st = GBA_PAIR_BAD_GUIDE;
                 if (i == 0) { qS = bq; tS = bt; }
                 else if (bq < qe || bt < te) st = GBA_PAIR_BAD_GUIDE;
+                else {
+                    const int64_t dr = (int64_t)(bt - te) - (int64_t)(bq - qe);
+                    drift_sum += (uint64_t)(dr < 0 ? -dr : dr);
+                }
                 qe = (uint64_t)bq + len; te = (uint64_t)bt + len;
             }
             if (st == GBA_PAIR_OK) { Q = (uint32_t)qe - qS; T = (uint32_t)te - tS; }
@@ -139,6 +149,14 @@ __global__ void k_meta(Dev d, int mode, int kband_k)
     d.status[p] = st; d.qS[p] = qS; d.tS[p] = tS; d.Q[p] = Q; d.T[p] = T;
     d.rows[p] = st == GBA_PAIR_OK ? Q + 1 : 0;
     d.cols[p] = st == GBA_PAIR_OK ? T + 1 : 0;
+    // Every DP row has one ROW word.  Columns enter the band at most T + 1 + sum|drift| times in
+    // total (the right edge only moves back when a widened gap ends), eight per EXT word, plus at
+    // most one partly filled EXT word per row that needs any (the boundary row, the first row of
+    // a gap, the first row of a block).  Rounded up to whole 4-word groups plus two groups that
+    // k_fill may prefetch past the end.
+    uint64_t wc = (uint64_t)Q + 1 + ((uint64_t)T + 1 + drift_sum) / 8 + 2ull * nb + 4;
+    wc = ((wc + 3) & ~3ull) + 8;
+    d.wcap[p] = st == GBA_PAIR_OK ? (uint32_t)wc : 0;
     d.span[p] = 0; d.ncells[p] = 0; d.lo_last[p] = 0; d.dp_score[p] = 0; d.cls[p] = NCLS;
 }
 
@@ -173,28 +191,31 @@ __device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t *sm, ui
     return sm[w] + inc - v;
 }
 
-// rows -> row_off, cols -> col_off (single block)
-__global__ __launch_bounds__(1024) void k_scan2(Dev d)
+// rows -> row_off, cols -> col_off, wcap -> word_off (single block)
+__global__ __launch_bounds__(1024) void k_scan3(Dev d)
 {
     __shared__ uint64_t sm[17];
-    uint64_t carry_r = 0, carry_c = 0;
+    uint64_t carry_r = 0, carry_c = 0, carry_w = 0;
     for (uint32_t base = 0; base < d.n; base += blockDim.x) {
         uint32_t p = base + threadIdx.x;
-        uint64_t r = p < d.n ? d.rows[p] : 0, c = p < d.n ? d.cols[p] : 0, tot;
-        uint64_t er = block_excl_scan(r, sm, &tot);
-        if (p < d.n) d.row_off[p] = carry_r + er;
+        const bool in = p < d.n;
+        uint64_t tot;
+        uint64_t e = block_excl_scan(in ? d.rows[p] : 0, sm, &tot);
+        if (in) d.row_off[p] = carry_r + e;
         carry_r += tot;
-        uint64_t ec = block_excl_scan(c, sm, &tot);
-        if (p < d.n) d.col_off[p] = carry_c + ec;
+        e = block_excl_scan(in ? d.cols[p] : 0, sm, &tot);
+        if (in) d.col_off[p] = carry_c + e;
         carry_c += tot;
+        e = block_excl_scan(in ? d.wcap[p] : 0, sm, &tot);
+        if (in) d.word_off[p] = carry_w + e;
+        carry_w += tot;
     }
-    if (threadIdx.x == 0) { d.plan->total_rows = carry_r; d.plan->total_cols = carry_c; }
+    if (threadIdx.x == 0) { d.plan->total_rows = carry_r; d.plan->total_cols = carry_c; d.plan->total_words = carry_w; }
 }
 
 // ---------------------------------------------------------------- k_pack
 // qc[i] = code of the query base of DP row i (1..Q), tc[j] = code of the target base of DP
-// column j (1..T); index 0 and the bytes past the end (16 for q, 48 for t) hold N so block loads
-// never leave the pair.
+// column j (1..T); index 0 and the 16 bytes past the end hold N.
 __global__ __launch_bounds__(256) void k_pack(Dev d)
 {
     const uint32_t p = blockIdx.x;
@@ -206,7 +227,7 @@ __global__ __launch_bounds__(256) void k_pack(Dev d)
     const uint8_t *t = d.t_arena + d.t_off[p] + d.tS[p];
     for (uint32_t i = threadIdx.x; i <= Q + 16; i += blockDim.x)
         qc[i] = (i >= 1 && i <= Q) ? (uint8_t)base_code(q[i - 1]) : (uint8_t)4;
-    for (uint32_t j = threadIdx.x; j <= T + 48; j += blockDim.x)
+    for (uint32_t j = threadIdx.x; j <= T + 16; j += blockDim.x)
         tc[j] = (j >= 1 && j <= T) ? (uint8_t)base_code(t[j - 1]) : (uint8_t)4;
 }
 
@@ -217,24 +238,24 @@ __global__ __launch_bounds__(256) void k_pack(Dev d)
 //   on the first row of a block w is replaced by max_band here, so target-only gaps stay connected)
 // Inside a block c advances by one per row with w = band; between blocks the common part of the
 // gap is walked diagonally and leftover query bases repeat the column, with
-// w = min(max_band, band + |drift|).  Emits one u32 per row:
-//   width (13 bits) | code of the row's query base << 13 | (lo_r - lo_{r-1}) << 16.
+// w = min(max_band, band + |drift|).  Emits the pair's guide stream: per row one ROW word, then
+// EXT words while more than three columns enter the band on the right.
 __global__ void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
 {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= d.n || d.status[p] != GBA_PAIR_OK) return;
     const uint32_t Q = d.Q[p], T = d.T[p], tS = d.tS[p];
-    uint32_t *g = d.guide + guide_offset(d, p);
+    uint32_t *g = d.stream + d.word_off[p];
+    const uint32_t wcap = d.wcap[p];
     const uint8_t *qc = d.qcodes + qc_offset(d, p);
+    const uint8_t *tc = d.tcodes + tc_offset(d, p);
     const int B = mode == GBA_MODE_KBAND ? kband_k : min(band, max_band);
-    uint32_t W0 = min(T, (uint32_t)B) + 1;
-    g[0] = W0;
-    uint64_t ncells = (uint64_t)B + 1;
-    uint32_t span = W0, lo_prev = 0;
+    uint32_t nw = 0;                             // words written
+    uint64_t ncells = 0;
+    uint32_t span = 0, lo_prev = 0, Wp = 0;
     bool wide = false;
     // block state machine
     const gba_block *bl = d.blocks + (mode == GBA_MODE_KBAND ? 0 : d.blk_off[p]);
-    const uint32_t nb = mode == GBA_MODE_KBAND ? 0 : d.n_blk[p];
     uint32_t b = 0, phase = 0, remaining = 0, c = 0, w = (uint32_t)B, step = 1;
     uint32_t bq = 0, bt = 0, blen = 0;          // current block
     if (mode != GBA_MODE_KBAND) {
@@ -243,50 +264,69 @@ __global__ void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
     }
     uint32_t ins_left = 0, wgap = 0;
     bool first = mode != GBA_MODE_KBAND;      // first row of a block: reaches back to the previous row's first column
-    for (uint32_t r = 1; r <= Q; r++) {
-        if (mode != GBA_MODE_KBAND) {
-            while (remaining == 0) {
-                if (phase == 0) {
-                    // leaving block b: set up the gap towards block b+1
-                    const uint32_t qe = bq + blen, te = bt + blen;
-                    b++;
-                    bq = bl[b].q_pos; bt = bl[b].t_pos; blen = bl[b].length;
-                    const uint32_t qGap = bq - qe, tGap = bt - te;
-                    const int drift = (int)tGap - (int)qGap;
-                    wgap = (uint32_t)min(max_band, band + (drift < 0 ? -drift : drift));
-                    const uint32_t diag = min(qGap, tGap);
-                    ins_left = qGap - diag;
-                    phase = 1; remaining = diag; w = wgap; step = 1;
-                } else if (phase == 1) {
-                    phase = 2; remaining = ins_left; w = wgap; step = 0;
-                } else {
-                    phase = 0; remaining = blen; w = (uint32_t)B; step = 1; first = true;
-                    c = bt - tS;                 // jump: the next row's centre is the block's first column
-                }
-            }
-            remaining--;
+    for (uint32_t r = 0; r <= Q; r++) {
+        uint32_t lo, W, tPre;
+        if (r == 0) {
+            lo = 0; W = min(T, (uint32_t)B) + 1; tPre = 0; w = (uint32_t)B;
         } else {
-            step = 1;
+            if (mode != GBA_MODE_KBAND) {
+                while (remaining == 0) {
+                    if (phase == 0) {
+                        // leaving block b: set up the gap towards block b+1
+                        const uint32_t qe = bq + blen, te = bt + blen;
+                        b++;
+                        bq = bl[b].q_pos; bt = bl[b].t_pos; blen = bl[b].length;
+                        const uint32_t qGap = bq - qe, tGap = bt - te;
+                        const int drift = (int)tGap - (int)qGap;
+                        wgap = (uint32_t)min(max_band, band + (drift < 0 ? -drift : drift));
+                        const uint32_t diag = min(qGap, tGap);
+                        ins_left = qGap - diag;
+                        phase = 1; remaining = diag; w = wgap; step = 1;
+                    } else if (phase == 1) {
+                        phase = 2; remaining = ins_left; w = wgap; step = 0;
+                    } else {
+                        phase = 0; remaining = blen; w = (uint32_t)B; step = 1; first = true;
+                        c = bt - tS;                 // jump: the next row's centre is the block's first column
+                    }
+                }
+                remaining--;
+            } else {
+                step = 1;
+            }
+            c += step;
+            tPre = min(first ? max((uint32_t)max_band, w) : w, c - lo_prev);
+            lo = c - tPre;
+            W = min(T, c + w) - lo + 1;
+            first = false;
         }
-        c += step;
-        const uint32_t tPre = min(first ? max((uint32_t)max_band, w) : w, c - lo_prev);
-        const uint32_t lo = c - tPre;
-        const uint32_t hi = min(T, c + w);
-        const uint32_t W = hi - lo + 1, dl = lo - lo_prev;
+        const uint32_t dl = lo - lo_prev;
         ncells += (uint64_t)tPre + w + 1;
         span = max(span, dl + W);
-        if (dl > 65535u || W > 8191u) wide = true;
-        g[r] = (W & 0x1fffu) | ((uint32_t)qc[r] << 13) | (dl << 16);
-        lo_prev = lo; first = false;
+        if (dl > 1023u || W > 1023u) wide = true;
+        // columns entering on the right: (hi_prev, hi] = lo_prev + Wp .. lo + W - 1
+        const uint32_t cnew = lo_prev + Wp;
+        uint32_t nnew = dl + W > Wp ? dl + W - Wp : 0;
+        uint32_t word = (W & ROW_W_MASK) | ((uint32_t)qc[r] << 10) | ((dl & 1023u) << 13);
+        for (uint32_t j = 0; j < 3 && j < nnew; j++) word |= (uint32_t)tc[cnew + j] << (23 + 3 * j);
+        if (nw < wcap) g[nw] = word;
+        nw++;
+        for (uint32_t j = 3; j < nnew; j += 8) {
+            uint32_t e = 0;
+            for (uint32_t x = 0; x < 8 && j + x < nnew; x++) e |= (uint32_t)tc[cnew + j + x] << (3 * x);
+            if (nw < wcap) g[nw] = e;
+            nw++;
+        }
+        lo_prev = lo; Wp = W;
     }
+    if (nw + 8 > wcap) wide = true;              // cannot happen (see k_meta); never overrun the stream
+    for (uint32_t x = nw; x < wcap; x++) g[x] = 0;
     d.span[p] = span; d.ncells[p] = ncells; d.lo_last[p] = lo_prev;
     if (wide) d.status[p] = GBA_PAIR_TOO_WIDE;
 }
 
 // ---------------------------------------------------------------- k_plan
-// Classes by LDS slots a pair needs (its largest shift + width): 32 / 64 / 128 / 256.  `order`
-// lists the OK pairs grouped by class (stable); rec_off is each pair's record offset in dwords
-// (a record row is slots/16 dwords).
+// `order` lists the OK pairs grouped by class (stable); rec_off is each pair's record offset in
+// dwords.  Pairs whose widest row needs more than the largest class are TOO_WIDE.
 __global__ __launch_bounds__(1024) void k_plan(Dev d)
 {
     __shared__ uint64_t sm[17];
@@ -297,7 +337,6 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d)
         uint32_t c = NCLS;
         if (d.status[p] == GBA_PAIR_OK) {
             const uint32_t s = d.span[p];
-            c = NCLS;
             for (int k = NCLS - 1; k >= 0; k--) if (s <= cls_slots(k)) c = (uint32_t)k;
             if (c == NCLS) d.status[p] = GBA_PAIR_TOO_WIDE;
             else atomicAdd(&cnt[c], 1u);
@@ -325,7 +364,7 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d)
             if (threadIdx.x == 0) run[k] += (uint32_t)tot;
             __syncthreads();
         }
-        const uint64_t rd = c < NCLS ? (uint64_t)d.rows[p] * cls_rw((int)c) : 0;
+        const uint64_t rd = c < NCLS ? (uint64_t)d.rows[p] * cls_rs((int)c) : 0;
         uint64_t e = block_excl_scan(rd, sm, &tot);
         if (p < d.n) d.rec_off[p] = carry + e;
         carry += tot;
@@ -335,32 +374,125 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d)
     if (threadIdx.x == 0) { d.plan->total_rec_dwords = carry; d.plan->total_cells = cells; }
 }
 
-// ---------------------------------------------------------------- k_fill_linear
-// One lane per pair, 64 pairs per wave, rows in lock step.  LDS holds one DP row per lane,
-// slot-major: word (slot s, lane l) at dword s*64 + l (conflict free: a wave access touches one
-// dword per lane in 64 consecutive banks, whatever the per-lane slot).  Slots are RELATIVE to the
-// row's first column: cell k of row i reads its vertical predecessor from slot k + shift (the
-// previous row's layout) and overwrites slot k; the read of a slot always precedes the write
-// that destroys it, so one row buffer is enough.  Columns that enter the band on the right get an
-// INFW word carrying their target base code before the row starts.
+// ---------------------------------------------------------------- k_fill
+// One LANE per pair, 64 pairs per wave.  Lanes are NOT in row lock step: every lane walks its own
+// guide stream.  One step of the (wave-uniform) loop lets each lane
+//   1. if its current row is finished, pop the next ROW word: new width / shift / query base,
+//      write the INFW words of up to three entering columns; or, if the row still has entering
+//      columns pending, pop an EXT word and write up to eight more;
+//   2. compute up to CAP cells of its current row (rows wider than CAP continue next step).
+// A lane with a 21-cell row and a lane with a 60-cell row therefore cost 2 and 4 steps, instead of
+// both paying for the widest row of the wave.
 //
-// A lane whose row is shorter than the wave's widest row skips whole groups of 4 cells; inside a
-// group it runs all 4 cells and prefetches the next group's 4 slots (up to 7 slots past its row
-// end).  Those accesses stay below KMAX + PAD_SLOTS and only produce record bits nobody reads.
-// One group of 4 cells per recursion step; the recursion is the (forced) full unroll of the
-// row loop, so slot offsets and record bit positions are immediates.
-template <int K4, int KMAX>
-struct CellGroups {
-    static __device__ __forceinline__ void run(const uint32_t *rd, uint32_t *wr, uint32_t W, uint32_t mlo, uint32_t mhi,
-                                               int32_t cU, int32_t cL, uint32_t diag, uint32_t left,
-                                               uint32_t u0, uint32_t u1, uint32_t u2, uint32_t u3, uint32_t *r)
+// LDS holds one DP row per lane, slot-major: word (slot s, lane l) at dword s*64 + l (conflict
+// free whatever the per-lane slot).  Slots are RELATIVE to the row's first column: cell k of a row
+// reads its vertical predecessor from slot k + shift (the previous row's layout) and overwrites
+// slot k; the read of a slot always precedes the write that destroys it, so one row buffer is
+// enough.  Inside a step a lane runs whole groups of 4 cells, up to 3 cells past its row end;
+// those cells only touch slots below slots + PAD_SLOTS and record bits nobody reads.
+//
+// Guide words arrive through an 8-word LDS FIFO per lane, refilled every 4 steps with a 4-word
+// group that was requested one refill earlier, so the only vector-memory wait covers a load
+// issued four steps before.  Record dwords are stored directly and never waited for.
+constexpr int LDS_TAB = 16, LDS_FIFO = 8 * 64;
+
+__global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, uint32_t slots)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x;
+    uint32_t *tab = lds + (slots + PAD_SLOTS) * 64;
+    uint32_t *fifo = tab + LDS_TAB;
+    if (lane < 10) tab[lane] = fc.mrow[lane];
+    __syncthreads();
+    const uint32_t cnt = d.plan->cls_count[cls], cbase = d.plan->cls_base[cls];
+    const uint32_t idx = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= cnt) return;
+    const bool live = idx < cnt;
+    const uint32_t p = d.order[cbase + (live ? idx : cnt - 1)];
+    const uint32_t Q = d.Q[p], T = d.T[p];
+    const uint32_t RS = 1u + slots / 16u;
+    const uint32_t *st = d.stream + d.word_off[p];
+    const uint32_t wcap = d.wcap[p];
+    uint32_t *rec = d.rec + d.rec_off[p] - RS;          // advanced by RS at every ROW word
+
+    // FIFO: words [wc, wi) are in LDS, group wi..wi+3 is in flight in pf
+    uint32_t wc = 0, wi = 8;
+    uint4 pf;
     {
-        if constexpr (K4 < KMAX) {
-            const bool in = (uint32_t)K4 < W;
-            if (__builtin_amdgcn_ballot_w64(in) == 0) return;
+        const uint4 a = *(const uint4 *)(st), b = *(const uint4 *)(st + 4);
+        pf = *(const uint4 *)(st + 8);
+        uint32_t *f = fifo + lane;
+        f[0] = a.x; f[64] = a.y; f[128] = a.z; f[192] = a.w; f[256] = b.x; f[320] = b.y; f[384] = b.z; f[448] = b.w;
+    }
+
+    uint32_t rows_left = live ? Q + 1 : 0;              // rows not yet started
+    uint32_t W = 0, dsh = 0, k0 = 0, Wp = 0, lo = 0;    // current row: width, shift, cells done; previous width, first column
+    uint32_t ext_left = 0, nnew_rem = 0, newslot = 0;
+    uint32_t diag = INFW, left = INFW, mlo = 0, mhi = 0;
+    bool first = true, finished = !live;
+    uint32_t final_word = INFW;
+
+    for (uint32_t it = 0; __any(!finished); it++) {
+        if ((it & 3u) == 0u && it != 0u) {
+            // refill: a lane that has at most 4 words left installs the prefetched group
+            if (wi - wc <= 4u) {
+                uint32_t *f = fifo + (wi & 7u) * 64 + lane;
+                f[0] = pf.x; f[64] = pf.y; f[128] = pf.z; f[192] = pf.w;
+                wi += 4;
+                if (wi + 4u <= wcap) pf = *(const uint4 *)(st + wi);
+            }
+        }
+        // ---- 1. word pop
+        const bool inrow = k0 < W;
+        const bool pop_row = !finished && !inrow && ext_left == 0u && rows_left > 0u;
+        const bool pop_ext = !finished && ext_left > 0u;
+        const uint32_t word = fifo[(wc & 7u) * 64 + lane];
+        if (pop_row) {
+            wc++; rows_left--;
+            lo += dsh; Wp = W;
+            W = word & ROW_W_MASK; dsh = (word >> 13) & 1023u;
+            const uint32_t q = (word >> 10) & 7u;
+            mlo = tab[q * 2]; mhi = tab[q * 2 + 1];
+            const uint32_t tot = dsh + W;
+            nnew_rem = tot > Wp ? tot - Wp : 0u;
+            uint32_t *ns = lds + Wp * 64 + lane;
+            if (nnew_rem > 0u) ns[0] = INFW | ((word >> 23) & 7u);
+            if (nnew_rem > 1u) ns[64] = INFW | ((word >> 26) & 7u);
+            if (nnew_rem > 2u) ns[128] = INFW | (word >> 29);
+            nnew_rem = nnew_rem > 3u ? nnew_rem - 3u : 0u;
+            ext_left = (nnew_rem + 7u) >> 3;
+            newslot = Wp + 3u;
+            k0 = 0;
+            // row 0 starts from "one deletion before column 0" so that cell j costs j deletions
+            left = first ? (uint32_t)(-fc.del * 32) : INFW;
+            first = false;
+            diag = INFW;
+            if (dsh >= 1u && dsh - 1u < Wp) diag = lds[(dsh - 1u) * 64 + lane];
+            rec += RS;
+            rec[0] = word & ROW_META_MASK;
+        } else if (pop_ext) {
+            wc++; ext_left--;
+            uint32_t *ns = lds + newslot * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if ((uint32_t)j < nnew_rem) ns[j * 64] = INFW | ((word >> (3 * j)) & 7u);
+            nnew_rem = nnew_rem > 8u ? nnew_rem - 8u : 0u;
+            newslot += 8u;
+        }
+        // ---- 2. up to CAP cells of the current row
+        const bool cells_ok = !finished && ext_left == 0u && k0 < W;
+        const uint32_t *rd = lds + (dsh + k0) * 64 + lane;
+        uint32_t *wr = lds + k0 * 64 + lane;
+        uint32_t ar = 0;
+        uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+        if (cells_ok) { u0 = rd[0]; u1 = rd[64]; u2 = rd[128]; u3 = rd[192]; }
+#pragma unroll
+        for (int K4 = 0; K4 < CAP; K4 += 4) {
+            const bool in = cells_ok && k0 + (uint32_t)K4 < W;
+            if (__builtin_amdgcn_ballot_w64(in) == 0) break;
             uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
             if (in) {
-                if constexpr (K4 + 4 < KMAX) {
+                if (K4 + 4 < CAP && k0 + (uint32_t)K4 + 4u < W) {
                     n0 = rd[(K4 + 4) * 64]; n1 = rd[(K4 + 5) * 64]; n2 = rd[(K4 + 6) * 64]; n3 = rd[(K4 + 7) * 64];
                 }
                 const uint32_t ups[4] = {u0, u1, u2, u3};
@@ -371,165 +503,26 @@ struct CellGroups {
                     const uint32_t sel = (up & 7u) | 0x0c0c0c00u;
                     const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, sel);
                     const int32_t m = (int32_t)((sb << 5) + diag);
-                    const int32_t u = (int32_t)up + cU;
-                    const int32_t l = (int32_t)left + cL;
+                    const int32_t u = (int32_t)up + fc.cU;
+                    const int32_t l = (int32_t)left + fc.cL;
                     const uint32_t best = (uint32_t)min(m, min(u, l));
-                    const uint32_t word = (up & 31u) | (best & ~31u);
-                    wr[k * 64] = word;
-                    // arrow = bits 3..4 of best -> record bits 2*(k%16)..
-                    const int sh = (k & 15) * 2 - 3;
-                    r[k >> 4] |= sh >= 0 ? (best & 0x18u) << (sh >= 0 ? sh : 0) : (best & 0x18u) >> (sh < 0 ? -sh : 0);
-                    diag = up; left = word;
+                    const uint32_t cw = (up & 31u) | (best & ~31u);
+                    wr[k * 64] = cw;
+                    // arrow = bits 3..4 of best -> record bits 2k..2k+1
+                    const int sh = k * 2 - 3;
+                    ar |= sh >= 0 ? (best & 0x18u) << (sh >= 0 ? sh : 0) : (best & 0x18u) >> (sh < 0 ? -sh : 0);
+                    diag = up; left = cw;
                 }
             }
-            CellGroups<K4 + 4, KMAX>::run(rd, wr, W, mlo, mhi, cU, cL, diag, left, n0, n1, n2, n3, r);
+            u0 = n0; u1 = n1; u2 = n2; u3 = n3;
         }
-    }
-};
-
-// Memory traffic is kept off the per-row critical path: guide words and target codes arrive in
-// chunks (CH rows / 32 columns at a time), are requested one chunk ahead into registers and
-// installed into small LDS rings at chunk boundaries, so the only vector-memory wait sits at a
-// boundary and covers loads issued a whole chunk earlier.  Record rows are stored directly and
-// never waited for.
-constexpr int CH = 8;                         // rows per guide chunk
-constexpr int LDS_TAB = 16, LDS_GBUF = 2 * CH * 64, LDS_TBUF = 16 * 64;
-
-template <int KMAX>
-__global__ __launch_bounds__(64) void k_fill_linear(Dev d, FillConst fc, uint32_t cls, uint32_t slots)
-{
-    extern __shared__ uint32_t lds[];
-    constexpr int RW = KMAX / 16;
-    const int lane = threadIdx.x;
-    uint32_t *tab = lds + (slots + PAD_SLOTS) * 64;
-    uint32_t *gbuf = tab + LDS_TAB;           // [2*CH rows][lane]: guide words of chunks c, c+1
-    uint32_t *tbuf = gbuf + LDS_GBUF;         // [2 blocks][8 dwords][lane]: target codes, 32 columns per block
-    if (lane < 10) tab[lane] = fc.mrow[lane];
-    __syncthreads();
-    const uint32_t cnt = d.plan->cls_count[cls], cbase = d.plan->cls_base[cls];
-    const uint32_t idx = blockIdx.x * 64 + lane;
-    if (blockIdx.x * 64 >= cnt) return;
-    const bool live = idx < cnt;
-    const uint32_t p = d.order[cbase + (live ? idx : cnt - 1)];
-    const uint32_t Q = live ? d.Q[p] : 0, T = d.T[p];
-    const uint32_t *g = d.guide + guide_offset(d, p);
-    uint32_t *rec = d.rec + d.rec_off[p];
-    const uint8_t *tc = d.tcodes + tc_offset(d, p);
-
-    uint32_t maxQ = Q;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxQ = max(maxQ, (uint32_t)__shfl_xor((int)maxQ, o, 64));
-
-    // ---- target-code blocks: the ring holds blocks tblk-1 and tblk, tp* is block tblk+1 in flight
-    auto tblock_ok = [&](uint32_t b) { return 32u * b <= T + 17u; };   // k_pack pads 48 codes past T
-    uint32_t tblk = 1;
-    uint4 tpa = make_uint4(0, 0, 0, 0), tpb = tpa;
-    {
-        const uint4 a = *(const uint4 *)(tc), b = *(const uint4 *)(tc + 16);
-        uint4 c4 = tpa, d4 = tpa;
-        if (tblock_ok(1)) { c4 = *(const uint4 *)(tc + 32); d4 = *(const uint4 *)(tc + 48); }
-        if (tblock_ok(2)) { tpa = *(const uint4 *)(tc + 64); tpb = *(const uint4 *)(tc + 80); }
-        uint32_t *t0 = tbuf + lane, *t1 = tbuf + 8 * 64 + lane;
-        t0[0] = a.x; t0[64] = a.y; t0[128] = a.z; t0[192] = a.w; t0[256] = b.x; t0[320] = b.y; t0[384] = b.z; t0[448] = b.w;
-        t1[0] = c4.x; t1[64] = c4.y; t1[128] = c4.z; t1[192] = c4.w; t1[256] = d4.x; t1[320] = d4.y; t1[384] = d4.z; t1[448] = d4.w;
-    }
-    auto tcode = [&](uint32_t c) -> uint32_t {
-        const uint32_t b = c >> 5;
-        if (b + 1u - tblk <= 1u)        // b == tblk-1 or b == tblk
-            return ((const uint8_t *)tbuf)[(((b & 1u) * 8u + ((c & 31u) >> 2)) * 64u + lane) * 4u + (c & 3u)];
-        return tc[c];                   // outside the ring (long jump or re-entry): direct load
-    };
-
-    // ---- guide chunks: LDS ring holds chunks c and c+1, gp* is chunk c+2 in flight
-    uint4 gpa = make_uint4(0, 0, 0, 0), gpb = gpa;
-    {
-        uint4 a = gpa, b = gpa, c4 = gpa, d4 = gpa;
-        if (live) { a = *(const uint4 *)(g); b = *(const uint4 *)(g + 4); }
-        if (live && CH <= Q) { c4 = *(const uint4 *)(g + CH); d4 = *(const uint4 *)(g + CH + 4); }
-        if (live && 2 * CH <= Q) { gpa = *(const uint4 *)(g + 2 * CH); gpb = *(const uint4 *)(g + 2 * CH + 4); }
-        uint32_t *g0 = gbuf + lane, *g1 = gbuf + CH * 64 + lane;
-        g0[0] = a.x; g0[64] = a.y; g0[128] = a.z; g0[192] = a.w; g0[256] = b.x; g0[320] = b.y; g0[384] = b.z; g0[448] = b.w;
-        g1[0] = c4.x; g1[64] = c4.y; g1[128] = c4.z; g1[192] = c4.w; g1[256] = d4.x; g1[320] = d4.y; g1[384] = d4.z; g1[448] = d4.w;
-    }
-
-    // ---- row 0: cell j costs j deletions, arrows Left
-    uint32_t Wp = live ? (gbuf[lane] & 0x1fffu) : 0, lo = 0;
-    for (uint32_t k = 0; __any(k < Wp); k++)
-        if (k < Wp) lds[k * 64 + lane] = ((uint32_t)((int32_t)k * fc.del) << 5) | tcode(k);
-    if (live) {
-        const uint32_t allL = fc.codeL * 0x55555555u;
-        for (int w = 0; w < RW; w++) rec[w] = allL;
-    }
-    uint32_t final_word = INFW;
-    if (live && Q == 0) final_word = lds[T * 64 + lane];
-
-    // two-row software pipeline over the guide ring: g1 = word of the next row, m* = matrix row of
-    // the current row
-    uint32_t g0w = gbuf[1 * 64 + lane];
-    uint32_t mlo = tab[((g0w >> 13) & 7u) * 2], mhi = tab[((g0w >> 13) & 7u) * 2 + 1];
-    uint32_t g1w = gbuf[2 * 64 + lane];
-
-    for (uint32_t i = 1; i <= maxQ; i++) {
-        if ((i & (CH - 1)) == 0) {
-            // chunk boundary (uniform): chunk c = i/CH starts; install chunk c+1, request chunk c+2
-            const uint32_t c = i / CH;
-            uint32_t *gi = gbuf + ((c + 1) & 1u) * (CH * 64) + lane;
-            gi[0] = gpa.x; gi[64] = gpa.y; gi[128] = gpa.z; gi[192] = gpa.w;
-            gi[256] = gpb.x; gi[320] = gpb.y; gi[384] = gpb.z; gi[448] = gpb.w;
-            if (live && (c + 2) * CH <= Q) { gpa = *(const uint4 *)(g + (c + 2) * CH); gpb = *(const uint4 *)(g + (c + 2) * CH + 4); }
-            // target codes: once the lane's next new column lies in block tblk, block tblk-1 is dead
-            if (lo + Wp >= 32u * tblk) {
-                uint32_t *ti = tbuf + ((tblk + 1u) & 1u) * (8 * 64) + lane;
-                ti[0] = tpa.x; ti[64] = tpa.y; ti[128] = tpa.z; ti[192] = tpa.w;
-                ti[256] = tpb.x; ti[320] = tpb.y; ti[384] = tpb.z; ti[448] = tpb.w;
-                tblk++;
-                if (tblock_ok(tblk + 1u)) {
-                    tpa = *(const uint4 *)(tc + 32u * (tblk + 1u));
-                    tpb = *(const uint4 *)(tc + 32u * (tblk + 1u) + 16u);
-                }
+        if (cells_ok) {
+            rec[1u + (k0 >> 4)] = ar;
+            k0 += CAP;
+            if (k0 >= W && rows_left == 0u) {
+                final_word = lds[(T - (lo + dsh)) * 64 + lane];
+                finished = true;
             }
-        }
-        const bool act = i <= Q;
-        const uint32_t gcur = g0w, cmlo = mlo, cmhi = mhi;
-        // fetch for the next rows (results are consumed after this row's cells)
-        g0w = g1w;
-        mlo = tab[((g0w >> 13) & 7u) * 2]; mhi = tab[((g0w >> 13) & 7u) * 2 + 1];
-        g1w = gbuf[((i + 2) & (2 * CH - 1)) * 64 + lane];     // row i+2 is always inside chunks c, c+1
-
-        const uint32_t W = act ? (gcur & 0x1fffu) : 0u, dsh = act ? (gcur >> 16) : 0u;
-        // columns entering on the right: previous-layout slots [Wp, dsh + W)
-        {
-            const uint32_t send = act ? dsh + W : 0u;
-            for (uint32_t s = Wp; __any(s < send); s += 4) {
-                if (s < send) {
-                    const uint32_t c0 = tcode(lo + s), c1 = tcode(lo + s + 1), c2 = tcode(lo + s + 2), c3 = tcode(lo + s + 3);
-                    uint32_t *w4 = lds + s * 64 + lane;      // slots up to send+2 < KMAX + PAD_SLOTS
-                    w4[0] = INFW | c0; w4[64] = INFW | c1; w4[128] = INFW | c2; w4[192] = INFW | c3;
-                }
-            }
-        }
-        uint32_t diag = INFW, left = INFW;
-        if (act && dsh >= 1) diag = lds[(dsh - 1) * 64 + lane];
-        const uint32_t *rd = lds + dsh * 64 + lane;
-        uint32_t *wr = lds + lane;
-        uint32_t r[RW];
-#pragma unroll
-        for (int w = 0; w < RW; w++) r[w] = 0;
-        // The vertical predecessors of a group are read one group ahead of the cells that use them
-        // (a read of slot s always precedes, in program order, the write that overwrites slot s:
-        // reads of group g+1 touch slots above every slot group g writes).
-        uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0;
-        if (0 < W) { u0 = rd[0]; u1 = rd[64]; u2 = rd[128]; u3 = rd[192]; }
-        CellGroups<0, KMAX>::run(rd, wr, W, cmlo, cmhi, fc.cU, fc.cL, diag, left, u0, u1, u2, u3, r);
-        if (act) {
-            uint32_t *rr = rec + (uint64_t)i * RW;
-            if constexpr (RW == 2) *(uint2 *)rr = make_uint2(r[0], r[1]);
-            else {
-#pragma unroll
-                for (int w = 0; w < RW; w += 4) *(uint4 *)(rr + w) = make_uint4(r[w], r[w + 1], r[w + 2], r[w + 3]);
-            }
-            lo += dsh; Wp = W;
-            if (i == Q) final_word = lds[(T - lo) * 64 + lane];
         }
     }
     if (live) {
@@ -555,35 +548,34 @@ __global__ __launch_bounds__(64) void k_traceback(Dev d, TbConst tc_, gba_pair_r
     gba_pair_result &R = res[p];
     if (d.status[p] != GBA_PAIR_OK) return;      // fill found the end cell unreachable
     const uint32_t Q = d.Q[p], T = d.T[p];
-    const uint32_t RW = cls_rw((int)d.cls[p]);
+    const uint32_t RS = cls_rs((int)d.cls[p]);
     const uint32_t *rec = d.rec + d.rec_off[p];
-    const uint32_t *g = d.guide + guide_offset(d, p);
     const uint8_t *tc = d.tcodes + tc_offset(d, p);
     gba_block *out = d.blk_scratch + d.row_off[p];
     const uint32_t cap = Q + 1;
     uint32_t i = Q, j = T, lo = d.lo_last[p], nb = 0, run = 0;
     uint32_t nM = 0, nX = 0, nI = 0, nD = 0;
     int32_t score = 0;
-    uint32_t gw = g[i], prev_op = 0;
+    uint32_t gw = rec[(uint64_t)i * RS], prev_op = 0;
     uint64_t steps = 0;
     const uint64_t limit = (uint64_t)Q + T + 2;
     int st = GBA_PAIR_OK;
     while (i > 0 || j > 0) {
         const uint32_t k = j - lo;
-        if (++steps > limit || k >= (gw & 0x1fffu)) { st = GBA_PAIR_UNREACHABLE; break; }
-        const uint32_t a = (rec[(uint64_t)i * RW + (k >> 4)] >> ((k & 15u) * 2u)) & 3u;
+        if (++steps > limit || k >= (gw & ROW_W_MASK)) { st = GBA_PAIR_UNREACHABLE; break; }
+        const uint32_t a = (rec[(uint64_t)i * RS + 1u + (k >> 4)] >> ((k & 15u) * 2u)) & 3u;
         if (a == 0) {
             if (i == 0 || j == 0) { st = GBA_PAIR_UNREACHABLE; break; }
-            const uint32_t qb = (gw >> 13) & 7u, tb = tc[j];
+            const uint32_t qb = (gw >> 10) & 7u, tb = tc[j];
             if (qb == tb) nM++; else nX++;
             score += sub[qb * 5 + tb];
-            run++; i--; j--; lo -= gw >> 16; gw = g[i]; prev_op = 0;
+            run++; i--; j--; lo -= (gw >> 13) & 1023u; gw = rec[(uint64_t)i * RS]; prev_op = 0;
         } else {
             if (run) { nb++; out[cap - nb] = gba_block{i, j, run}; run = 0; }
             uint32_t op;
             if (a == tc_.codeU) {
                 if (i == 0) { st = GBA_PAIR_UNREACHABLE; break; }
-                nI++; i--; lo -= gw >> 16; gw = g[i]; op = 1;
+                nI++; i--; lo -= (gw >> 13) & 1023u; gw = rec[(uint64_t)i * RS]; op = 1;
             } else if (a == tc_.codeL) {
                 if (j == 0) { st = GBA_PAIR_UNREACHABLE; break; }
                 nD++; j--; op = 2;
@@ -667,7 +659,7 @@ struct gba_ctx {
     FillConst fc;
     TbConst tbc;
     // device scratch (grow-only)
-    Buf b_pair32[12], b_pair64[4], b_dp, b_plan, b_guide, b_qc, b_tc, b_rec, b_blk, b_needed;
+    Buf b_pair32[13], b_pair64[5], b_dp, b_plan, b_guide, b_qc, b_tc, b_rec, b_blk, b_needed;
     // staging for the host-pointer path
     Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res, s_out;
     Plan *h_plan = nullptr;          // pinned
@@ -706,18 +698,17 @@ void release(Buf &b)
     b.ptr = nullptr; b.cap = 0;
 }
 
-template <int KMAX>
 int launch_fill(gba_ctx *c, const Dev &d, uint32_t cls, uint32_t count, hipStream_t st)
 {
     const uint32_t slots = cls_slots((int)cls);
-    const size_t lds = ((size_t)(slots + PAD_SLOTS) * 64 + LDS_TAB + LDS_GBUF + LDS_TBUF) * 4;
+    const size_t lds = ((size_t)(slots + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        const size_t mx = ((size_t)(KMAX + PAD_SLOTS) * 64 + LDS_TAB + LDS_GBUF + LDS_TBUF) * 4;
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_fill_linear<KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
+        const size_t mx = ((size_t)(cls_slots(NCLS - 1) + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_fill_linear<KMAX>, dim3((count + 63) / 64), dim3(64), lds, st, d, c->fc, cls, slots);
+    hipLaunchKernelGGL(k_fill, dim3((count + 63) / 64), dim3(64), lds, st, d, c->fc, cls, slots);
     HIPCHK(c, hipGetLastError());
     return GBA_OK;
 }
@@ -730,8 +721,8 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     out->blocks_needed = 0;
     if (n == 0) return GBA_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    for (int i = 0; i < 12; i++) { int rc = ensure(c, c->b_pair32[i], (size_t)n * 4); if (rc) return rc; }
-    for (int i = 0; i < 4; i++) { int rc = ensure(c, c->b_pair64[i], (size_t)n * 8); if (rc) return rc; }
+    for (int i = 0; i < 13; i++) { int rc = ensure(c, c->b_pair32[i], (size_t)n * 4); if (rc) return rc; }
+    for (int i = 0; i < 5; i++) { int rc = ensure(c, c->b_pair64[i], (size_t)n * 8); if (rc) return rc; }
     { int rc = ensure(c, c->b_plan, sizeof(Plan)); if (rc) return rc; }
     { int rc = ensure(c, c->b_needed, 8); if (rc) return rc; }
     Dev d;
@@ -747,8 +738,10 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     d.span = (uint32_t *)c->b_pair32[7].ptr; d.lo_last = (uint32_t *)c->b_pair32[8].ptr;
     d.cls = (uint32_t *)c->b_pair32[9].ptr; d.order = (uint32_t *)c->b_pair32[10].ptr;
     d.dp_score = (int32_t *)c->b_pair32[11].ptr;
+    d.wcap = (uint32_t *)c->b_pair32[12].ptr;
     d.row_off = (uint64_t *)c->b_pair64[0].ptr; d.col_off = (uint64_t *)c->b_pair64[1].ptr;
     d.rec_off = (uint64_t *)c->b_pair64[2].ptr; d.ncells = (uint64_t *)c->b_pair64[3].ptr;
+    d.word_off = (uint64_t *)c->b_pair64[4].ptr;
     d.plan = (Plan *)c->b_plan.ptr;
     const gba_scoring &sc = c->sc;
     const bool timing = (c->flags & GBA_FLAG_TIMING) != 0;
@@ -757,15 +750,15 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
 
     if (timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
     hipLaunchKernelGGL(k_meta, dim3(g256), dim3(256), 0, s, d, sc.mode, sc.kband_k);
-    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(1024), 0, s, d);
+    hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, s, d);
     HIPCHK(c, hipMemcpyAsync(c->h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const uint64_t rows = c->h_plan->total_rows, cols = c->h_plan->total_cols;
-    { int rc = ensure(c, c->b_guide, (size_t)(rows + 32ull * n + 64) * 4); if (rc) return rc; }
+    { int rc = ensure(c, c->b_guide, (size_t)(c->h_plan->total_words + 16) * 4); if (rc) return rc; }
     { int rc = ensure(c, c->b_qc, (size_t)(rows + 32ull * n + 64)); if (rc) return rc; }
-    { int rc = ensure(c, c->b_tc, (size_t)(cols + 64ull * n + 128)); if (rc) return rc; }
+    { int rc = ensure(c, c->b_tc, (size_t)(cols + 32ull * n + 64)); if (rc) return rc; }
     { int rc = ensure(c, c->b_blk, (size_t)(rows + 4) * sizeof(gba_block)); if (rc) return rc; }
-    d.guide = (uint32_t *)c->b_guide.ptr;
+    d.stream = (uint32_t *)c->b_guide.ptr;
     d.qcodes = (uint8_t *)c->b_qc.ptr; d.tcodes = (uint8_t *)c->b_tc.ptr;
     d.blk_scratch = (gba_block *)c->b_blk.ptr;
 
@@ -793,11 +786,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
             const int a = (int)(launches % NAUX);
             hipStream_t st = c->aux[a];
             if (!used[a]) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0)); used[a] = true; }
-            int rc;
-            if (k == 0) rc = launch_fill<32>(c, d, 0, cnt, st);
-            else if (k == 1) rc = launch_fill<64>(c, d, 1, cnt, st);
-            else if (k == 2) rc = launch_fill<128>(c, d, 2, cnt, st);
-            else rc = launch_fill<256>(c, d, 3, cnt, st);
+            int rc = launch_fill(c, d, (uint32_t)k, cnt, st);
             if (rc) return rc;
             launches++;
         }
@@ -935,7 +924,7 @@ int gba_set_scoring(gba_ctx *c, const gba_scoring *s)
     }
     f.cU = s->ins * 32 + (int32_t)(codeU << 3) + BIASW;
     f.cL = s->del * 32 + (int32_t)(codeL << 3);
-    f.del = s->del; f.codeL = codeL;
+    f.del = s->del;
     TbConst &t = c->tbc;
     for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) t.sub[a * 5 + b] = s->sub[a][b];
     t.ins = s->stats_ins; t.del = s->stats_del; t.aopen = s->stats_affine_open; t.aext = s->stats_affine_extend;
