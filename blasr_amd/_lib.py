@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgba.so")
+LIB_PATH = os.environ.get("GBA_LIB", os.path.join(_HERE, "libgba.so"))   # GBA_LIB: experiment builds
 
 # return codes / statuses / modes (include/gba.h)
 OK, E_INVALID, E_NOMEM, E_HIP, E_NOSPACE, E_UNSUPPORTED, E_STATE = 0, -1, -2, -3, -4, -5, -6

@@ -42,10 +42,9 @@ constexpr uint32_t MAX_COLS = 1u << 20;
 // Classes of the lane-per-pair fill kernel: a pair's class is the smallest LDS row buffer
 // (32 << class slots) that holds its widest "shift + width".  Each non-empty class is one launch.
 constexpr int NCLS = 4;
-constexpr int PAD_SLOTS = 4;                 // a lane runs up to 3 cells past its row end (see k_fill)
-constexpr int CAP = 16;                      // cells per lane per step of k_fill
+constexpr int PAD_SLOTS = 3;                 // a lane runs up to 3 cells past its row end (see k_fill)
+constexpr int CAP = 32;                      // cells per lane per step of k_fill
 __host__ __device__ constexpr uint32_t cls_slots(int c) { return 32u << c; }
-__host__ __device__ constexpr uint32_t cls_rs(int c) { return 1u + (2u << c); }   // record dwords per row: meta + arrows
 
 // Guide stream words (one stream per pair, built by k_guide, consumed by k_fill):
 //   ROW  width[0:10) | query base code[10:13) | shift of the first column[13:23) | codes of the
@@ -72,19 +71,19 @@ struct Dev {                  // per-batch device state, SoA per pair
     const gba_block *blocks;
     // per pair
     int32_t *status;
-    uint32_t *qS, *tS, *Q, *T, *rows, *cols, *wcap, *span, *lo_last, *cls, *order;
+    uint32_t *qS, *tS, *Q, *T, *rows, *cols, *wcap, *span, *lo_last, *cls, *order, *recdw;
     uint64_t *row_off, *col_off, *word_off, *rec_off, *ncells;
     int32_t *dp_score;
     Plan *plan;
     // arenas
     uint32_t *stream;         // guide stream words
     uint8_t *qcodes, *tcodes;
-    uint32_t *rec;            // traceback records: per DP row one meta dword + 2-bit arrows
+    uint32_t *rec;            // traceback records, per DP row: ceil(width/16) dwords of 2-bit arrows, then one meta dword
     gba_block *blk_scratch;
 };
 
 struct FillConst {
-    uint32_t mrow[10];        // per query code: 8 bytes = biased substitution costs against target codes 0..7
+    uint32_t mrow[10];        // per query code: 8 bytes = 0, then biased substitution costs against target codes A,C,G,T,N,N,N
     int32_t cU, cL;           // (cost << 5) + (arrow code << 3) [+ BIASW for the vertical move]
     int32_t del;
 };
@@ -157,7 +156,7 @@ __global__ void k_meta(Dev d, int mode, int kband_k)
     uint64_t wc = (uint64_t)Q + 1 + ((uint64_t)T + 1 + drift_sum) / 8 + 2ull * nb + 4;
     wc = ((wc + 3) & ~3ull) + 8;
     d.wcap[p] = st == GBA_PAIR_OK ? (uint32_t)wc : 0;
-    d.span[p] = 0; d.ncells[p] = 0; d.lo_last[p] = 0; d.dp_score[p] = 0; d.cls[p] = NCLS;
+    d.span[p] = 0; d.ncells[p] = 0; d.lo_last[p] = 0; d.dp_score[p] = 0; d.cls[p] = NCLS; d.recdw[p] = 0;
 }
 
 // ---------------------------------------------------------------- block-wide scan helpers (1024 threads)
@@ -214,8 +213,9 @@ __global__ __launch_bounds__(1024) void k_scan3(Dev d)
 }
 
 // ---------------------------------------------------------------- k_pack
-// qc[i] = code of the query base of DP row i (1..Q), tc[j] = code of the target base of DP
-// column j (1..T); index 0 and the 16 bytes past the end hold N.
+// qc[i] = code (0..4) of the query base of DP row i (1..Q); tc[j] = code + 1 (1..5) of the target
+// base of DP column j (1..T), the form the fill kernel's byte-table lookup takes; index 0 and the
+// 16 bytes past the end hold N.
 __global__ __launch_bounds__(256) void k_pack(Dev d)
 {
     const uint32_t p = blockIdx.x;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void k_pack(Dev d)
     for (uint32_t i = threadIdx.x; i <= Q + 16; i += blockDim.x)
         qc[i] = (i >= 1 && i <= Q) ? (uint8_t)base_code(q[i - 1]) : (uint8_t)4;
     for (uint32_t j = threadIdx.x; j <= T + 16; j += blockDim.x)
-        tc[j] = (j >= 1 && j <= T) ? (uint8_t)base_code(t[j - 1]) : (uint8_t)4;
+        tc[j] = (j >= 1 && j <= T) ? (uint8_t)(base_code(t[j - 1]) + 1u) : (uint8_t)5;
 }
 
 // ---------------------------------------------------------------- k_guide
@@ -247,12 +247,19 @@ __global__ void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
     const uint32_t Q = d.Q[p], T = d.T[p], tS = d.tS[p];
     uint32_t *g = d.stream + d.word_off[p];
     const uint32_t wcap = d.wcap[p];
-    const uint8_t *qc = d.qcodes + qc_offset(d, p);
+    const uint32_t *qc4 = (const uint32_t *)(d.qcodes + qc_offset(d, p));    // 4 codes per dword
     const uint8_t *tc = d.tcodes + tc_offset(d, p);
     const int B = mode == GBA_MODE_KBAND ? kband_k : min(band, max_band);
-    uint32_t nw = 0;                             // words written
+    uint32_t nw = 0;                             // words produced
+    uint4 ob = make_uint4(0, 0, 0, 0);           // words are written 16 bytes at a time
+    auto push = [&](uint32_t word) {
+        const uint32_t s = nw & 3u;
+        if (s == 0) ob.x = word; else if (s == 1) ob.y = word; else if (s == 2) ob.z = word; else ob.w = word;
+        nw++;
+        if ((nw & 3u) == 0u && nw <= wcap) *(uint4 *)(g + nw - 4) = ob;
+    };
     uint64_t ncells = 0;
-    uint32_t span = 0, lo_prev = 0, Wp = 0;
+    uint32_t span = 0, lo_prev = 0, Wp = 0, recdw = 0;
     bool wide = false;
     // block state machine
     const gba_block *bl = d.blocks + (mode == GBA_MODE_KBAND ? 0 : d.blk_off[p]);
@@ -262,10 +269,11 @@ __global__ void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
         bq = bl[0].q_pos; bt = bl[0].t_pos; blen = bl[0].length;
         remaining = blen; c = bt - tS; step = 1;    // c is pre-incremented below: first row centre = bt - tS + 1
     }
-    uint32_t ins_left = 0, wgap = 0;
+    uint32_t ins_left = 0, wgap = 0, qword = 0;
     bool first = mode != GBA_MODE_KBAND;      // first row of a block: reaches back to the previous row's first column
     for (uint32_t r = 0; r <= Q; r++) {
         uint32_t lo, W, tPre;
+        if ((r & 3u) == 0u) qword = qc4[r >> 2];
         if (r == 0) {
             lo = 0; W = min(T, (uint32_t)B) + 1; tPre = 0; w = (uint32_t)B;
         } else {
@@ -302,31 +310,35 @@ __global__ void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
         const uint32_t dl = lo - lo_prev;
         ncells += (uint64_t)tPre + w + 1;
         span = max(span, dl + W);
+        recdw += 1u + ((W + 15u) >> 4);
         if (dl > 1023u || W > 1023u) wide = true;
         // columns entering on the right: (hi_prev, hi] = lo_prev + Wp .. lo + W - 1
         const uint32_t cnew = lo_prev + Wp;
-        uint32_t nnew = dl + W > Wp ? dl + W - Wp : 0;
-        uint32_t word = (W & ROW_W_MASK) | ((uint32_t)qc[r] << 10) | ((dl & 1023u) << 13);
+        const uint32_t nnew = dl + W > Wp ? dl + W - Wp : 0;
+        const uint32_t qcode = (qword >> ((r & 3u) * 8u)) & 7u;
+        uint32_t word = (W & ROW_W_MASK) | (qcode << 10) | ((dl & 1023u) << 13);
         for (uint32_t j = 0; j < 3 && j < nnew; j++) word |= (uint32_t)tc[cnew + j] << (23 + 3 * j);
-        if (nw < wcap) g[nw] = word;
-        nw++;
+        push(word);
         for (uint32_t j = 3; j < nnew; j += 8) {
             uint32_t e = 0;
             for (uint32_t x = 0; x < 8 && j + x < nnew; x++) e |= (uint32_t)tc[cnew + j + x] << (3 * x);
-            if (nw < wcap) g[nw] = e;
-            nw++;
+            push(e);
         }
         lo_prev = lo; Wp = W;
     }
     if (nw + 8 > wcap) wide = true;              // cannot happen (see k_meta); never overrun the stream
-    for (uint32_t x = nw; x < wcap; x++) g[x] = 0;
-    d.span[p] = span; d.ncells[p] = ncells; d.lo_last[p] = lo_prev;
+    // flush the partial group and zero the rest of the pair's stream (whole 4-word groups)
+    const uint32_t nreal = nw;
+    while ((nw & 3u) != 0u) push(0);
+    (void)nreal;
+    for (uint32_t x = nw; x + 4 <= wcap; x += 4) *(uint4 *)(g + x) = make_uint4(0, 0, 0, 0);
+    d.span[p] = span; d.ncells[p] = ncells; d.lo_last[p] = lo_prev; d.recdw[p] = recdw;
     if (wide) d.status[p] = GBA_PAIR_TOO_WIDE;
 }
 
 // ---------------------------------------------------------------- k_plan
 // `order` lists the OK pairs grouped by class (stable); rec_off is each pair's record offset in
-// dwords.  Pairs whose widest row needs more than the largest class are TOO_WIDE.
+// dwords (4 spare dwords precede every pair: the traceback reads 16-byte windows ending at a row).  Pairs whose widest row needs more than the largest class are TOO_WIDE.
 __global__ __launch_bounds__(1024) void k_plan(Dev d)
 {
     __shared__ uint64_t sm[17];
@@ -364,9 +376,9 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d)
             if (threadIdx.x == 0) run[k] += (uint32_t)tot;
             __syncthreads();
         }
-        const uint64_t rd = c < NCLS ? (uint64_t)d.rows[p] * cls_rs((int)c) : 0;
+        const uint64_t rd = c < NCLS ? (uint64_t)d.recdw[p] + 4u : 0;
         uint64_t e = block_excl_scan(rd, sm, &tot);
-        if (p < d.n) d.rec_off[p] = carry + e;
+        if (p < d.n) d.rec_off[p] = carry + e + 4u;
         carry += tot;
         block_excl_scan(c < NCLS ? d.ncells[p] : 0, sm, &tot);
         cells += tot;
@@ -391,10 +403,12 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d)
 // enough.  Inside a step a lane runs whole groups of 4 cells, up to 3 cells past its row end;
 // those cells only touch slots below slots + PAD_SLOTS and record bits nobody reads.
 //
-// Guide words arrive through an 8-word LDS FIFO per lane, refilled every 4 steps with a 4-word
-// group that was requested one refill earlier, so the only vector-memory wait covers a load
-// issued four steps before.  Record dwords are stored directly and never waited for.
-constexpr int LDS_TAB = 16, LDS_FIFO = 8 * 64;
+// Guide words arrive through a 12-word LDS ring per lane, refilled every 4th step with a 4-word
+// group that is requested at the start of that step and installed at its end; that wait is the
+// only vector-memory wait in the loop.  Record dwords are stored directly.
+constexpr int FIFO_WORDS = 12;
+constexpr int LDS_TAB = 16, LDS_FIFO = FIFO_WORDS * 64;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, uint32_t slots)
 {
@@ -410,49 +424,55 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     const bool live = idx < cnt;
     const uint32_t p = d.order[cbase + (live ? idx : cnt - 1)];
     const uint32_t Q = d.Q[p], T = d.T[p];
-    const uint32_t RS = 1u + slots / 16u;
     const uint32_t *st = d.stream + d.word_off[p];
     const uint32_t wcap = d.wcap[p];
-    uint32_t *rec = d.rec + d.rec_off[p] - RS;          // advanced by RS at every ROW word
+    uint32_t *rec = d.rec + d.rec_off[p];               // next record dword of this pair
 
-    // FIFO: words [wc, wi) are in LDS, group wi..wi+3 is in flight in pf
-    uint32_t wc = 0, wi = 8;
-    uint4 pf;
+    // FIFO: stream words [wc, wi) are in the LDS ring; hs / is are the ring slots of words wc / wi.
+    // At least two words are buffered at the start of every step (see the refill rule below), so
+    // the word after the one a step pops can be peeked during that step.
+    uint32_t wc = 0, wi = FIFO_WORDS, hs = 0, is = 0;
     {
-        const uint4 a = *(const uint4 *)(st), b = *(const uint4 *)(st + 4);
-        pf = *(const uint4 *)(st + 8);
+        const uint4 a = *(const uint4 *)(st), b = *(const uint4 *)(st + 4), c4 = *(const uint4 *)(st + 8);
         uint32_t *f = fifo + lane;
         f[0] = a.x; f[64] = a.y; f[128] = a.z; f[192] = a.w; f[256] = b.x; f[320] = b.y; f[384] = b.z; f[448] = b.w;
+        f[512] = c4.x; f[576] = c4.y; f[640] = c4.z; f[704] = c4.w;
     }
 
     uint32_t rows_left = live ? Q + 1 : 0;              // rows not yet started
     uint32_t W = 0, dsh = 0, k0 = 0, Wp = 0, lo = 0;    // current row: width, shift, cells done; previous width, first column
     uint32_t ext_left = 0, nnew_rem = 0, newslot = 0;
-    uint32_t diag = INFW, left = INFW, mlo = 0, mhi = 0;
+    uint32_t diag = INFW, left = INFW, mlo = 0, mhi = 0, meta = 0;
     bool first = true, finished = !live;
     uint32_t final_word = INFW;
+    // the next word of the stream and the matrix row of its query base are fetched one step ahead
+    uint32_t nword = fifo[lane];                       // ring slot hs = 0
+    uint32_t nmlo = tab[((nword >> 10) & 7u) * 2], nmhi = tab[((nword >> 10) & 7u) * 2 + 1];
+    uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0;            // vertical predecessors of the next 4 cells
 
     for (uint32_t it = 0; __any(!finished); it++) {
-        if ((it & 3u) == 0u && it != 0u) {
-            // refill: a lane that has at most 4 words left installs the prefetched group
-            if (wi - wc <= 4u) {
-                uint32_t *f = fifo + (wi & 7u) * 64 + lane;
-                f[0] = pf.x; f[64] = pf.y; f[128] = pf.z; f[192] = pf.w;
-                wi += 4;
-                if (wi + 4u <= wcap) pf = *(const uint4 *)(st + wi);
+        // Refill (every 4th step): a lane with at most 8 of its 12 ring words left requests the next
+        // 4-word group now and installs it at the end of this step; a step pops at most one word, so
+        // a lane never starts a step with fewer than two.  The load is issued from inline asm so
+        // that no wait for it (or for the record stores) is placed anywhere else in the loop.
+        const bool refill = (it & 3u) == 0u && wi - wc <= 8u && wi + 4u <= wcap;
+        u32x4 pf = {0, 0, 0, 0};
+        if ((it & 3u) == 0u) {
+            if (refill) {
+                const uint32_t *src = st + wi;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pf) : "v"(src) : "memory");
             }
         }
         // ---- 1. word pop
         const bool inrow = k0 < W;
         const bool pop_row = !finished && !inrow && ext_left == 0u && rows_left > 0u;
         const bool pop_ext = !finished && ext_left > 0u;
-        const uint32_t word = fifo[(wc & 7u) * 64 + lane];
+        const uint32_t word = nword;
         if (pop_row) {
-            wc++; rows_left--;
+            wc++; hs = hs == FIFO_WORDS - 1 ? 0u : hs + 1u; rows_left--;
             lo += dsh; Wp = W;
             W = word & ROW_W_MASK; dsh = (word >> 13) & 1023u;
-            const uint32_t q = (word >> 10) & 7u;
-            mlo = tab[q * 2]; mhi = tab[q * 2 + 1];
+            mlo = nmlo; mhi = nmhi;
             const uint32_t tot = dsh + W;
             nnew_rem = tot > Wp ? tot - Wp : 0u;
             uint32_t *ns = lds + Wp * 64 + lane;
@@ -468,10 +488,9 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
             first = false;
             diag = INFW;
             if (dsh >= 1u && dsh - 1u < Wp) diag = lds[(dsh - 1u) * 64 + lane];
-            rec += RS;
-            rec[0] = word & ROW_META_MASK;
+            meta = word & ROW_META_MASK;
         } else if (pop_ext) {
-            wc++; ext_left--;
+            wc++; hs = hs == FIFO_WORDS - 1 ? 0u : hs + 1u; ext_left--;
             uint32_t *ns = lds + newslot * 64 + lane;
 #pragma unroll
             for (int j = 0; j < 8; j++)
@@ -479,20 +498,24 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
             nnew_rem = nnew_rem > 8u ? nnew_rem - 8u : 0u;
             newslot += 8u;
         }
+        const bool popped = pop_row || pop_ext;
+        // peek the following word (not needed before the next step)
+        nword = fifo[hs * 64 + lane];
+        nmlo = tab[((nword >> 10) & 7u) * 2]; nmhi = tab[((nword >> 10) & 7u) * 2 + 1];
         // ---- 2. up to CAP cells of the current row
         const bool cells_ok = !finished && ext_left == 0u && k0 < W;
         const uint32_t *rd = lds + (dsh + k0) * 64 + lane;
         uint32_t *wr = lds + k0 * 64 + lane;
-        uint32_t ar = 0;
-        uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0;
-        if (cells_ok) { u0 = rd[0]; u1 = rd[64]; u2 = rd[128]; u3 = rd[192]; }
+        uint32_t ar0 = 0, ar1 = 0;
+        // a lane that continues a row already holds these from the previous step's look-ahead
+        if (cells_ok && (popped || k0 == 0u)) { u0 = rd[0]; u1 = rd[64]; u2 = rd[128]; u3 = rd[192]; }
 #pragma unroll
         for (int K4 = 0; K4 < CAP; K4 += 4) {
             const bool in = cells_ok && k0 + (uint32_t)K4 < W;
             if (__builtin_amdgcn_ballot_w64(in) == 0) break;
-            uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
             if (in) {
-                if (K4 + 4 < CAP && k0 + (uint32_t)K4 + 4u < W) {
+                uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+                if (k0 + (uint32_t)K4 + 4u < W) {
                     n0 = rd[(K4 + 4) * 64]; n1 = rd[(K4 + 5) * 64]; n2 = rd[(K4 + 6) * 64]; n3 = rd[(K4 + 7) * 64];
                 }
                 const uint32_t ups[4] = {u0, u1, u2, u3};
@@ -500,8 +523,7 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                 for (int kk = 0; kk < 4; kk++) {
                     const int k = K4 + kk;
                     const uint32_t up = ups[kk];
-                    const uint32_t sel = (up & 7u) | 0x0c0c0c00u;
-                    const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, sel);
+                    const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, up & 7u);   // selector bytes 1..3 = 0 read the zero byte
                     const int32_t m = (int32_t)((sb << 5) + diag);
                     const int32_t u = (int32_t)up + fc.cU;
                     const int32_t l = (int32_t)left + fc.cL;
@@ -509,19 +531,36 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                     const uint32_t cw = (up & 31u) | (best & ~31u);
                     wr[k * 64] = cw;
                     // arrow = bits 3..4 of best -> record bits 2k..2k+1
-                    const int sh = k * 2 - 3;
-                    ar |= sh >= 0 ? (best & 0x18u) << (sh >= 0 ? sh : 0) : (best & 0x18u) >> (sh < 0 ? -sh : 0);
+                    const int sh = (k & 15) * 2 - 3;
+                    const uint32_t ab = sh >= 0 ? (best & 0x18u) << (sh >= 0 ? sh : 0) : (best & 0x18u) >> (sh < 0 ? -sh : 0);
+                    if (k < 16) ar0 |= ab; else ar1 |= ab;
                     diag = up; left = cw;
                 }
+                u0 = n0; u1 = n1; u2 = n2; u3 = n3;
             }
-            u0 = n0; u1 = n1; u2 = n2; u3 = n3;
         }
         if (cells_ok) {
-            rec[1u + (k0 >> 4)] = ar;
+            // record: the arrow dwords of this step, then the row's meta dword once the row is done
+            rec[0] = ar0;
+            const bool two = k0 + 16u < W;
+            if (two) rec[1] = ar1;
+            rec += two ? 2 : 1;
             k0 += CAP;
-            if (k0 >= W && rows_left == 0u) {
-                final_word = lds[(T - (lo + dsh)) * 64 + lane];
-                finished = true;
+            if (k0 >= W) {
+                rec[0] = meta;
+                rec++;
+                if (rows_left == 0u) {
+                    final_word = lds[(T - (lo + dsh)) * 64 + lane];
+                    finished = true;
+                }
+            }
+        }
+        if ((it & 3u) == 0u) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf) : : "memory");
+            if (refill) {
+                uint32_t *f = fifo + is * 64 + lane;
+                f[0] = pf.x; f[64] = pf.y; f[128] = pf.z; f[192] = pf.w;
+                wi += 4; is = is == FIFO_WORDS - 4 ? 0u : is + 4u;
             }
         }
     }
@@ -548,41 +587,63 @@ __global__ __launch_bounds__(64) void k_traceback(Dev d, TbConst tc_, gba_pair_r
     gba_pair_result &R = res[p];
     if (d.status[p] != GBA_PAIR_OK) return;      // fill found the end cell unreachable
     const uint32_t Q = d.Q[p], T = d.T[p];
-    const uint32_t RS = cls_rs((int)d.cls[p]);
     const uint32_t *rec = d.rec + d.rec_off[p];
-    const uint8_t *tc = d.tcodes + tc_offset(d, p);
+    const uint32_t *tc4 = (const uint32_t *)(d.tcodes + tc_offset(d, p));   // 4 column codes per dword
     gba_block *out = d.blk_scratch + d.row_off[p];
     const uint32_t cap = Q + 1;
     uint32_t i = Q, j = T, lo = d.lo_last[p], nb = 0, run = 0;
     uint32_t nM = 0, nX = 0, nI = 0, nD = 0;
     int32_t score = 0;
-    uint32_t gw = rec[(uint64_t)i * RS], prev_op = 0;
+    uint32_t prev_op = 0;
     uint64_t steps = 0;
     const uint64_t limit = (uint64_t)Q + T + 2;
     int st = GBA_PAIR_OK;
+    // A row's record is [arrow dwords][meta]; ptr is the meta dword of the current row.  One 16-byte
+    // load ending at ptr brings the meta and the row's last three arrow dwords (all of them for rows
+    // up to 48 cells); rows are walked last to first, so the loads run backwards through memory.
+    int64_t ptr = (int64_t)d.recdw[p] - 1;
+    uint32_t w0, w1, w2, gw;                      // arrow dwords at ptr-3, ptr-2, ptr-1; meta
+    auto load_row = [&]() {
+        const uint32_t *q = rec + ptr - 3;
+        w0 = q[0]; w1 = q[1]; w2 = q[2]; gw = q[3];
+    };
+    load_row();
+    uint32_t tword = tc4[j >> 2];
     while (i > 0 || j > 0) {
-        const uint32_t k = j - lo;
-        if (++steps > limit || k >= (gw & ROW_W_MASK)) { st = GBA_PAIR_UNREACHABLE; break; }
-        const uint32_t a = (rec[(uint64_t)i * RS + 1u + (k >> 4)] >> ((k & 15u) * 2u)) & 3u;
+        const uint32_t k = j - lo, W = gw & ROW_W_MASK;
+        if (++steps > limit || k >= W) { st = GBA_PAIR_UNREACHABLE; break; }
+        const uint32_t n = (W + 15u) >> 4;        // arrow dwords of this row
+        const uint32_t back = n - (k >> 4);       // the wanted dword sits `back` dwords before the meta
+        uint32_t aw = back == 1u ? w2 : back == 2u ? w1 : w0;
+        if (back > 3u) aw = rec[ptr - back];
+        const uint32_t a = (aw >> ((k & 15u) * 2u)) & 3u;
+        bool newrow = false;
         if (a == 0) {
             if (i == 0 || j == 0) { st = GBA_PAIR_UNREACHABLE; break; }
-            const uint32_t qb = (gw >> 10) & 7u, tb = tc[j];
+            const uint32_t qb = (gw >> 10) & 7u, tb = ((tword >> ((j & 3u) * 8u)) & 7u) - 1u;
             if (qb == tb) nM++; else nX++;
             score += sub[qb * 5 + tb];
-            run++; i--; j--; lo -= (gw >> 13) & 1023u; gw = rec[(uint64_t)i * RS]; prev_op = 0;
+            run++; i--; j--; prev_op = 0; newrow = true;
+            if ((j & 3u) == 3u) tword = tc4[j >> 2];
         } else {
             if (run) { nb++; out[cap - nb] = gba_block{i, j, run}; run = 0; }
             uint32_t op;
             if (a == tc_.codeU) {
                 if (i == 0) { st = GBA_PAIR_UNREACHABLE; break; }
-                nI++; i--; lo -= (gw >> 13) & 1023u; gw = rec[(uint64_t)i * RS]; op = 1;
+                nI++; i--; op = 1; newrow = true;
             } else if (a == tc_.codeL) {
                 if (j == 0) { st = GBA_PAIR_UNREACHABLE; break; }
                 nD++; j--; op = 2;
+                if ((j & 3u) == 3u) tword = tc4[j >> 2];
             } else { st = GBA_PAIR_UNREACHABLE; break; }
             if (tc_.affine) { if (prev_op != op) score += tc_.aopen; score += tc_.aext; }
             else score += op == 1 ? tc_.ins : tc_.del;
             prev_op = op;
+        }
+        if (newrow) {
+            lo -= (gw >> 13) & 1023u;
+            ptr -= (int64_t)n + 1;
+            load_row();
         }
     }
     if (run) { nb++; out[cap - nb] = gba_block{i, j, run}; }
@@ -659,7 +720,7 @@ struct gba_ctx {
     FillConst fc;
     TbConst tbc;
     // device scratch (grow-only)
-    Buf b_pair32[13], b_pair64[5], b_dp, b_plan, b_guide, b_qc, b_tc, b_rec, b_blk, b_needed;
+    Buf b_pair32[14], b_pair64[5], b_dp, b_plan, b_guide, b_qc, b_tc, b_rec, b_blk, b_needed;
     // staging for the host-pointer path
     Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res, s_out;
     Plan *h_plan = nullptr;          // pinned
@@ -721,7 +782,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     out->blocks_needed = 0;
     if (n == 0) return GBA_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    for (int i = 0; i < 13; i++) { int rc = ensure(c, c->b_pair32[i], (size_t)n * 4); if (rc) return rc; }
+    for (int i = 0; i < 14; i++) { int rc = ensure(c, c->b_pair32[i], (size_t)n * 4); if (rc) return rc; }
     for (int i = 0; i < 5; i++) { int rc = ensure(c, c->b_pair64[i], (size_t)n * 8); if (rc) return rc; }
     { int rc = ensure(c, c->b_plan, sizeof(Plan)); if (rc) return rc; }
     { int rc = ensure(c, c->b_needed, 8); if (rc) return rc; }
@@ -739,6 +800,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     d.cls = (uint32_t *)c->b_pair32[9].ptr; d.order = (uint32_t *)c->b_pair32[10].ptr;
     d.dp_score = (int32_t *)c->b_pair32[11].ptr;
     d.wcap = (uint32_t *)c->b_pair32[12].ptr;
+    d.recdw = (uint32_t *)c->b_pair32[13].ptr;
     d.row_off = (uint64_t *)c->b_pair64[0].ptr; d.col_off = (uint64_t *)c->b_pair64[1].ptr;
     d.rec_off = (uint64_t *)c->b_pair64[2].ptr; d.ncells = (uint64_t *)c->b_pair64[3].ptr;
     d.word_off = (uint64_t *)c->b_pair64[4].ptr;
@@ -774,18 +836,23 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     gba_pair_result *res = out->pairs;
     hipLaunchKernelGGL(k_results_init, dim3(g256), dim3(256), 0, s, d, res);
     if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
-    // One launch per non-empty class, spread over auxiliary streams so that classes with few
-    // waves share the GPU instead of running back to back.
+    // One launch per non-empty class, widest class first: the few waves of a wide class run
+    // longest and overlap with the bulk.  The first two launches go to auxiliary streams (the
+    // runtime exposes few hardware queues), the rest to the main stream.
     uint32_t launches = 0;
     {
         HIPCHK(c, hipEventRecord(c->ev_fork, s));
         bool used[NAUX] = {};
-        for (int k = 0; k < NCLS; k++) {
+        for (int k = NCLS - 1; k >= 0; k--) {
             const uint32_t cnt = pl.cls_count[k];
             if (!cnt) continue;
-            const int a = (int)(launches % NAUX);
-            hipStream_t st = c->aux[a];
-            if (!used[a]) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0)); used[a] = true; }
+            hipStream_t st = s;
+            if (launches < 2) {
+                const int a = (int)launches;
+                st = c->aux[a];
+                HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0));
+                used[a] = true;
+            }
             int rc = launch_fill(c, d, (uint32_t)k, cnt, st);
             if (rc) return rc;
             launches++;
@@ -918,8 +985,9 @@ int gba_set_scoring(gba_ctx *c, const gba_scoring *s)
     FillConst &f = c->fc;
     for (int a = 0; a < 5; a++) {
         uint32_t lo = 0, hi = 0;
-        for (int b = 0; b < 4; b++) lo |= (uint32_t)(uint8_t)(s->sub[a][b] + 128) << (8 * b);
-        hi = (uint32_t)(uint8_t)(s->sub[a][4] + 128) * 0x01010101u;   // codes 4..7 all read the N column
+        // byte 0 is zero: the lookup's unused selector bytes read it; bytes 1..5 = A,C,G,T,N
+        for (int b = 0; b < 3; b++) lo |= (uint32_t)(uint8_t)(s->sub[a][b] + 128) << (8 * (b + 1));
+        hi = (uint32_t)(uint8_t)(s->sub[a][3] + 128) | ((uint32_t)(uint8_t)(s->sub[a][4] + 128) * 0x01010100u);
         f.mrow[2 * a] = lo; f.mrow[2 * a + 1] = hi;
     }
     f.cU = s->ins * 32 + (int32_t)(codeU << 3) + BIASW;
