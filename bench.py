@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=131072, help="pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=106496, help="pairs per GPU per step")
     ap.add_argument("--workload", default="c2_10kb_linear")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")

@@ -26,10 +26,24 @@ def build_libgba(force=False, extra=()):
     return LIBGBA
 
 
+HOST_DEMO = os.path.join(_HERE, "host", "refine_demo")
+
+
+def build_host_demo(force=False):
+    """C++ driver of the host shim (blasr_amd/host/gba_refine.hpp), used by the tests."""
+    src = os.path.join(_HERE, "host", "refine_demo.cpp")
+    hdr = os.path.join(_HERE, "host", "gba_refine.hpp")
+    if force or _stale(HOST_DEMO, [src, hdr, HDR, LIBGBA]):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-o", HOST_DEMO, src,
+                               "-L" + _HERE, "-lgba", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"])
+    return HOST_DEMO
+
+
 def build_all(force=False):
     from . import synth
     build_libgba(force)
     synth.build(force)
+    build_host_demo(force)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,171 @@
+// gba_refine.hpp -- C++ host side of the refine path over the C ABI (include/gba.h).
+//
+// Header-only mirror of the reference's RefineAlignments / RefineAlignment for the guided
+// branch (/root/reference/iblasr/BlasrUtilsImpl.hpp:620-923).  The reference calls
+// GuidedAlign once per candidate; here the candidates of any number of reads are collected
+// into one struct-of-arrays batch, aligned by one gba_submit / gba_wait, and copied back with
+// the same field updates as :745-772.  Types are the minimal stand-ins for the libcpp classes
+// the reference uses at this seam (blasr::Block, T_AlignmentCandidate, MappingParameters).
+#ifndef GBA_REFINE_HPP
+#define GBA_REFINE_HPP
+
+#include <algorithm>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/gba.h"
+
+namespace gba {
+
+struct Block { uint32_t qPos, tPos, length; };      // layout-compatible with gba_block
+
+// hot-path subset of iblasr/MappingParameters.h (defaults :207-381, bandSize after MakeSane :501-503)
+struct MappingParameters {
+    int insertion = 4, deletion = 5, indel = 5;
+    int match = -5, mismatch = 6;
+    bool affineAlign = false;
+    int affineOpen = 10, affineExtend = 0;
+    int guidedAlignBandSize = 10, bandSize = 16, maxBandSize = 250;
+    bool useGuidedAlign = true, refineAlignments = true, sortRefinedAlignments = true;
+    int maxScore = -200;
+    int tieBreak = GBA_TIE_DIAG_LEFT_UP;
+};
+
+// the T_AlignmentCandidate fields RefineAlignment reads and writes (:678-772)
+struct AlignmentCandidate {
+    std::string tAlignedSeq, qAlignedSeq;
+    uint32_t tAlignedSeqPos = 0, qAlignedSeqPos = 0, tAlignedSeqLength = 0, qAlignedSeqLength = 0;
+    uint32_t qPos = 0, tPos = 0;
+    std::vector<Block> blocks;
+    int score = 0;
+    uint64_t nCells = 0;
+    uint32_t nMatch = 0, nMismatch = 0, nIns = 0, nDel = 0;
+    float pctSimilarity = 0;
+    int status = 0;
+};
+
+inline gba_scoring ScoringFromParams(const MappingParameters &p)
+{
+    gba_scoring s{};
+    for (int a = 0; a < 5; a++)
+        for (int b = 0; b < 5; b++) s.sub[a][b] = (a == 4 || b == 4) ? 0 : (a == b ? p.match : p.mismatch);
+    // distScoreFn(SMRTDistanceMatrix, params.deletion, params.insertion), read as ctor(ins, del): :630-631
+    s.ins = p.deletion; s.del = p.insertion;
+    s.stats_ins = s.stats_del = p.indel;                       // distScoreFn2, :633-634
+    s.affine_open = p.affineOpen; s.affine_extend = p.affineExtend;
+    s.band = p.affineAlign ? p.bandSize : p.guidedAlignBandSize;   // :706-731
+    s.max_band = p.maxBandSize;
+    s.mode = p.affineAlign ? GBA_MODE_AFFINE : GBA_MODE_LINEAR;
+    s.tie_break = p.tieBreak;
+    s.stats_affine = p.affineAlign ? 1 : 0;
+    return s;
+}
+
+// Collects (read, candidate) pairs of many reads, runs them as one batch.
+class RefineBatch {
+public:
+    explicit RefineBatch(gba_ctx *ctx) : ctx_(ctx) {}
+
+    // slicing rules of :693-703; a candidate without blocks is kept with n_blk = 0 (:681)
+    void Add(const std::string &read, AlignmentCandidate *c)
+    {
+        const uint64_t qbase = Intern(read);
+        cands_.push_back(c);
+        const size_t nb = c->blocks.size();
+        if (nb == 0) {
+            q_off_.push_back(0); q_len_.push_back(0); t_off_.push_back(0); t_len_.push_back(0);
+            b_off_.push_back(0); n_blk_.push_back(0);
+            return;
+        }
+        const Block &first = c->blocks.front(), &last = c->blocks.back();
+        const uint32_t tl = last.tPos + last.length - first.tPos, ql = last.qPos + last.length;
+        if ((uint64_t)c->qAlignedSeqPos + c->qPos + ql > read.size() || (uint64_t)c->tPos + tl > c->tAlignedSeq.size())
+            throw std::out_of_range("candidate guide exceeds its sequences");
+        q_off_.push_back(qbase + c->qAlignedSeqPos + c->qPos); q_len_.push_back(ql);
+        t_off_.push_back(t_arena_.size()); t_len_.push_back(tl);
+        t_arena_.append(c->tAlignedSeq, c->tPos, tl);
+        b_off_.push_back(blocks_.size()); n_blk_.push_back((uint32_t)nb);
+        for (const Block &b : c->blocks) blocks_.push_back(gba_block{b.qPos, b.tPos, b.length});
+    }
+
+    // one submit/wait for everything added; copy-back of :733-772.  Returns the gba return code.
+    int Run(const MappingParameters &params)
+    {
+        const uint32_t n = (uint32_t)cands_.size();
+        if (n == 0) return GBA_OK;
+        gba_scoring sc = ScoringFromParams(params);
+        int rc = gba_set_scoring(ctx_, &sc);
+        if (rc != GBA_OK) return rc;
+        if (t_arena_.empty()) t_arena_.push_back('N');
+        if (blocks_.empty()) blocks_.push_back(gba_block{0, 0, 0});
+        gba_batch b{};
+        b.n_pairs = n;
+        b.q_arena = (const uint8_t *)q_arena_.data(); b.q_off = q_off_.data(); b.q_len = q_len_.data();
+        b.t_arena = (const uint8_t *)t_arena_.data(); b.t_off = t_off_.data(); b.t_len = t_len_.data();
+        b.blocks = blocks_.data(); b.blk_off = b_off_.data(); b.n_blk = n_blk_.data();
+        b.q_arena_bytes = q_arena_.size(); b.t_arena_bytes = t_arena_.size(); b.n_blocks_total = blocks_.size();
+        if ((rc = gba_submit(ctx_, &b)) != GBA_OK) return rc;
+        uint64_t cap = n;
+        for (uint32_t l : q_len_) cap += l;
+        std::vector<gba_pair_result> pairs(n);
+        std::vector<gba_block> out(cap);
+        gba_results r{pairs.data(), out.data(), cap, 0};
+        if ((rc = gba_wait(ctx_, &r)) != GBA_OK) return rc;
+        for (uint32_t i = 0; i < n; i++) {
+            AlignmentCandidate &c = *cands_[i];
+            const gba_pair_result &p = pairs[i];
+            c.status = p.status;
+            if (p.status != GBA_PAIR_OK) continue;
+            c.blocks.resize(p.n_blk);
+            for (uint32_t k = 0; k < p.n_blk; k++) {
+                const gba_block &g = out[p.blk_off + k];
+                c.blocks[k] = Block{g.q_pos, g.t_pos, g.length};
+            }
+            c.nMatch = p.n_match; c.nMismatch = p.n_mismatch; c.nIns = p.n_ins; c.nDel = p.n_del;
+            const uint64_t cols = (uint64_t)p.n_match + p.n_mismatch + p.n_ins + p.n_del;
+            c.pctSimilarity = cols ? (float)(p.n_match * 2.0 / (2.0 * cols) * 100.0) : 0.f;
+            c.score = p.score; c.nCells = p.ncells;
+            c.tAlignedSeq = t_arena_.substr(t_off_[i], t_len_[i]);
+            c.qAlignedSeq = q_arena_.substr(q_off_[i], q_len_[i]);
+            c.tAlignedSeqPos += c.tPos; c.qAlignedSeqPos += c.qPos;
+            c.tPos = p.t_pos; c.qPos = p.q_pos;
+            c.tAlignedSeqLength = t_len_[i]; c.qAlignedSeqLength = q_len_[i];
+        }
+        return GBA_OK;
+    }
+
+private:
+    uint64_t Intern(const std::string &read)
+    {
+        if (last_read_ == read.data() && last_len_ == read.size()) return last_base_;
+        last_read_ = read.data(); last_len_ = read.size(); last_base_ = q_arena_.size();
+        q_arena_ += read;
+        return last_base_;
+    }
+    gba_ctx *ctx_;
+    std::vector<AlignmentCandidate *> cands_;
+    std::string q_arena_, t_arena_;
+    std::vector<gba_block> blocks_;
+    std::vector<uint64_t> q_off_, t_off_, b_off_;
+    std::vector<uint32_t> q_len_, t_len_, n_blk_;
+    const char *last_read_ = nullptr; size_t last_len_ = 0; uint64_t last_base_ = 0;
+};
+
+// RefineAlignments for ONE read (:905-923): all its candidates in one batch, then the re-sort.
+inline int RefineAlignments(const std::string &read, std::vector<AlignmentCandidate *> &alignmentPtrs,
+                            const MappingParameters &params, gba_ctx *ctx)
+{
+    if (!params.refineAlignments || !params.useGuidedAlign) return GBA_E_UNSUPPORTED;
+    RefineBatch batch(ctx);
+    for (AlignmentCandidate *c : alignmentPtrs) batch.Add(read, c);
+    const int rc = batch.Run(params);
+    if (rc == GBA_OK && params.sortRefinedAlignments)
+        std::stable_sort(alignmentPtrs.begin(), alignmentPtrs.end(),
+                         [](const AlignmentCandidate *a, const AlignmentCandidate *b) { return a->score < b->score; });
+    return rc;
+}
+
+}  // namespace gba
+#endif

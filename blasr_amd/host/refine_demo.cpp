@@ -1,0 +1,38 @@
+// Small driver of gba_refine.hpp used by the tests: reads pairs from stdin
+//   n
+//   read  target  nblk  (qPos tPos len)*nblk      -- one candidate per line, one read each
+// refines them in ONE batch and prints per candidate: status score nCells qPos tPos nblk blocks...
+#include <cstdio>
+#include <iostream>
+
+#include "gba_refine.hpp"
+
+int main()
+{
+    size_t n;
+    if (!(std::cin >> n)) return 2;
+    std::vector<std::string> reads(n);
+    std::vector<gba::AlignmentCandidate> cands(n);
+    for (size_t i = 0; i < n; i++) {
+        size_t nb;
+        std::cin >> reads[i] >> cands[i].tAlignedSeq >> nb;
+        cands[i].blocks.resize(nb);
+        for (auto &b : cands[i].blocks) std::cin >> b.qPos >> b.tPos >> b.length;
+    }
+    gba_ctx *ctx = nullptr;
+    gba_config cfg{0, 0, nullptr};
+    int rc = gba_create(&ctx, &cfg);
+    if (rc != GBA_OK) { std::fprintf(stderr, "gba_create: %s\n", gba_strerror(rc)); return 1; }
+    gba::MappingParameters params;
+    gba::RefineBatch batch(ctx);
+    for (size_t i = 0; i < n; i++) batch.Add(reads[i], &cands[i]);
+    rc = batch.Run(params);
+    if (rc != GBA_OK) { std::fprintf(stderr, "Run: %s\n", gba_strerror(rc)); return 1; }
+    for (auto &c : cands) {
+        std::printf("%d %d %llu %u %u %zu", c.status, c.score, (unsigned long long)c.nCells, c.qPos, c.tPos, c.blocks.size());
+        for (auto &b : c.blocks) std::printf(" %u %u %u", b.qPos, b.tPos, b.length);
+        std::printf("\n");
+    }
+    gba_destroy(ctx);
+    return 0;
+}
