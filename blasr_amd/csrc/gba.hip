@@ -38,10 +38,11 @@ constexpr uint32_t INFW = 0x40000000u;       // "no path" cell word
 constexpr int32_t UNREACH = 0x20000000;      // unbiased words at or above this are unreachable
 constexpr int32_t BIASW = 128 << 5;          // per-row bias of the byte substitution table
 constexpr uint32_t MAX_ROWS = 65535;         // keeps biased words inside int32 (see gba_set_scoring)
+constexpr uint32_t MAX_ROWS_AFFINE = 32767;  // affine words carry one more tag bit
 constexpr uint32_t MAX_COLS = 1u << 20;
 // Classes of the lane-per-pair fill kernel: a pair's class is the smallest LDS row buffer
 // (32 << class slots) that holds its widest "shift + width".  Each non-empty class is one launch.
-constexpr int NCLS = 4;
+constexpr int NCLS = 5;                      // 32, 64, 128, 256, 512 slots (affine: up to 256, it keeps two rings)
 constexpr int PAD_SLOTS = 3;                 // a lane runs up to 3 cells past its row end (see k_fill)
 constexpr int CAP = 32;                      // cells per lane per step of k_fill
 __host__ __device__ constexpr uint32_t cls_slots(int c) { return 32u << c; }
@@ -84,14 +85,17 @@ struct Dev {                  // per-batch device state, SoA per pair
 
 struct FillConst {
     uint32_t mrow[10];        // per query code: 8 bytes = 0, then biased substitution costs against target codes A,C,G,T,N,N,N
-    int32_t cU, cL;           // (cost << 5) + (arrow code << 3) [+ BIASW for the vertical move]
+    int32_t cU, cL;           // (cost << S) + (arrow code << 3) [+ row bias for the vertical move]; S = 5 linear, 6 affine
     int32_t del;
+    // affine only: gap-state constants and the row-0 diagonal that makes cell (0,0) cost 0
+    int32_t cIO, cIE, cDO, cDE, diag0;
 };
 
 struct TbConst {
     int32_t sub[25];
     int32_t ins, del, aopen, aext, affine;
     uint32_t codeU, codeL;
+    int32_t mode;
 };
 
 __device__ __forceinline__ uint32_t base_code(uint8_t c)
@@ -144,7 +148,7 @@ __global__ void k_meta(Dev d, int mode, int kband_k)
             if (st == GBA_PAIR_OK) { Q = (uint32_t)qe - qS; T = (uint32_t)te - tS; }
         }
     }
-    if (st == GBA_PAIR_OK && (Q > MAX_ROWS || T > MAX_COLS)) st = GBA_PAIR_TOO_LONG;
+    if (st == GBA_PAIR_OK && (Q > (mode == GBA_MODE_AFFINE ? MAX_ROWS_AFFINE : MAX_ROWS) || T > MAX_COLS)) st = GBA_PAIR_TOO_LONG;
     d.status[p] = st; d.qS[p] = qS; d.tS[p] = tS; d.Q[p] = Q; d.T[p] = T;
     d.rows[p] = st == GBA_PAIR_OK ? Q + 1 : 0;
     d.cols[p] = st == GBA_PAIR_OK ? T + 1 : 0;
@@ -310,7 +314,7 @@ __global__ void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
         const uint32_t dl = lo - lo_prev;
         ncells += (uint64_t)tPre + w + 1;
         span = max(span, dl + W);
-        recdw += 1u + ((W + 15u) >> 4);
+        recdw += 1u + (mode == GBA_MODE_AFFINE ? (W + 3u) >> 2 : (W + 15u) >> 4);
         if (dl > 1023u || W > 1023u) wide = true;
         // columns entering on the right: (hi_prev, hi] = lo_prev + Wp .. lo + W - 1
         const uint32_t cnew = lo_prev + Wp;
@@ -338,8 +342,9 @@ __global__ void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
 
 // ---------------------------------------------------------------- k_plan
 // `order` lists the OK pairs grouped by class (stable); rec_off is each pair's record offset in
-// dwords (4 spare dwords precede every pair: the traceback reads 16-byte windows ending at a row).  Pairs whose widest row needs more than the largest class are TOO_WIDE.
-__global__ __launch_bounds__(1024) void k_plan(Dev d)
+// dwords (4 spare dwords precede every pair: the traceback reads 16-byte windows ending at a row;
+// 8 follow it: the fill kernel stores whole steps and lets the next store overwrite the tail).  Pairs whose widest row needs more than the largest class are TOO_WIDE.
+__global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls)
 {
     __shared__ uint64_t sm[17];
     __shared__ uint32_t cnt[NCLS + 1], base[NCLS + 1], run[NCLS + 1];
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d)
         uint32_t c = NCLS;
         if (d.status[p] == GBA_PAIR_OK) {
             const uint32_t s = d.span[p];
-            for (int k = NCLS - 1; k >= 0; k--) if (s <= cls_slots(k)) c = (uint32_t)k;
+            for (int k = ncls - 1; k >= 0; k--) if (s <= cls_slots(k)) c = (uint32_t)k;
             if (c == NCLS) d.status[p] = GBA_PAIR_TOO_WIDE;
             else atomicAdd(&cnt[c], 1u);
         }
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d)
             if (threadIdx.x == 0) run[k] += (uint32_t)tot;
             __syncthreads();
         }
-        const uint64_t rd = c < NCLS ? (uint64_t)d.recdw[p] + 4u : 0;
+        const uint64_t rd = c < NCLS ? (uint64_t)d.recdw[p] + 12u : 0;
         uint64_t e = block_excl_scan(rd, sm, &tot);
         if (p < d.n) d.rec_off[p] = carry + e + 4u;
         carry += tot;
@@ -410,11 +415,19 @@ constexpr int FIFO_WORDS = 12;
 constexpr int LDS_TAB = 16, LDS_FIFO = FIFO_WORDS * 64;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// Affine variant (AFF): the match state M and the insertion-gap state I of the previous row both
+// live in LDS (two rings), the deletion-gap state D travels along the row in a register.  Words
+// are score << 6 | arrow << 3 | low bits; the gap states put their own open/extend bit in bit 2
+// (I) and bit 1 (D).  Records hold one byte per cell: M arrow (bits 3..5), I bit, D bit.
+template <bool AFF>
 __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, uint32_t slots)
 {
     extern __shared__ uint32_t lds[];
+    constexpr int SH = AFF ? 6 : 5;                     // score shift of a cell word
+    constexpr uint32_t TAGS = (1u << SH) - 1u;
     const int lane = threadIdx.x;
-    uint32_t *tab = lds + (slots + PAD_SLOTS) * 64;
+    const uint32_t SL = slots + PAD_SLOTS;              // slots of one ring
+    uint32_t *tab = lds + (AFF ? 2u : 1u) * SL * 64;
     uint32_t *fifo = tab + LDS_TAB;
     if (lane < 10) tab[lane] = fc.mrow[lane];
     __syncthreads();
@@ -427,6 +440,7 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     const uint32_t *st = d.stream + d.word_off[p];
     const uint32_t wcap = d.wcap[p];
     uint32_t *rec = d.rec + d.rec_off[p];               // next record dword of this pair
+    const uint32_t IOFF = SL * 64;                      // dword offset of the I ring
 
     // FIFO: stream words [wc, wi) are in the LDS ring; hs / is are the ring slots of words wc / wi.
     // At least two words are buffered at the start of every step (see the refill rule below), so
@@ -442,13 +456,14 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     uint32_t rows_left = live ? Q + 1 : 0;              // rows not yet started
     uint32_t W = 0, dsh = 0, k0 = 0, Wp = 0, lo = 0;    // current row: width, shift, cells done; previous width, first column
     uint32_t ext_left = 0, nnew_rem = 0, newslot = 0;
-    uint32_t diag = INFW, left = INFW, mlo = 0, mhi = 0, meta = 0;
+    uint32_t diag = INFW, left = INFW, leftD = INFW, mlo = 0, mhi = 0, meta = 0;
     bool first = true, finished = !live;
     uint32_t final_word = INFW;
     // the next word of the stream and the matrix row of its query base are fetched one step ahead
     uint32_t nword = fifo[lane];                       // ring slot hs = 0
     uint32_t nmlo = tab[((nword >> 10) & 7u) * 2], nmhi = tab[((nword >> 10) & 7u) * 2 + 1];
-    uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0;            // vertical predecessors of the next 4 cells
+    uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0;            // vertical predecessors (M) of the next 4 cells
+    uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;            // vertical predecessors (I), affine only
 
     for (uint32_t it = 0; __any(!finished); it++) {
         // Refill (every 4th step): a lane with at most 8 of its 12 ring words left requests the next
@@ -476,25 +491,28 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
             const uint32_t tot = dsh + W;
             nnew_rem = tot > Wp ? tot - Wp : 0u;
             uint32_t *ns = lds + Wp * 64 + lane;
-            if (nnew_rem > 0u) ns[0] = INFW | ((word >> 23) & 7u);
-            if (nnew_rem > 1u) ns[64] = INFW | ((word >> 26) & 7u);
-            if (nnew_rem > 2u) ns[128] = INFW | (word >> 29);
+            if (nnew_rem > 0u) { ns[0] = INFW | ((word >> 23) & 7u); if constexpr (AFF) ns[IOFF] = INFW; }
+            if (nnew_rem > 1u) { ns[64] = INFW | ((word >> 26) & 7u); if constexpr (AFF) ns[IOFF + 64] = INFW; }
+            if (nnew_rem > 2u) { ns[128] = INFW | (word >> 29); if constexpr (AFF) ns[IOFF + 128] = INFW; }
             nnew_rem = nnew_rem > 3u ? nnew_rem - 3u : 0u;
             ext_left = (nnew_rem + 7u) >> 3;
             newslot = Wp + 3u;
             k0 = 0;
-            // row 0 starts from "one deletion before column 0" so that cell j costs j deletions
-            left = first ? (uint32_t)(-fc.del * 32) : INFW;
-            first = false;
-            diag = INFW;
+            diag = INFW; left = INFW; leftD = INFW;
             if (dsh >= 1u && dsh - 1u < Wp) diag = lds[(dsh - 1u) * 64 + lane];
+            if (first) {
+                // row 0: linear starts from "one deletion before column 0" so that cell j costs j
+                // deletions; affine makes the diagonal candidate of cell (0,0) cost exactly 0
+                if constexpr (AFF) diag = (uint32_t)fc.diag0; else left = (uint32_t)(-fc.del * 32);
+            }
+            first = false;
             meta = word & ROW_META_MASK;
         } else if (pop_ext) {
             wc++; hs = hs == FIFO_WORDS - 1 ? 0u : hs + 1u; ext_left--;
             uint32_t *ns = lds + newslot * 64 + lane;
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                if ((uint32_t)j < nnew_rem) ns[j * 64] = INFW | ((word >> (3 * j)) & 7u);
+                if ((uint32_t)j < nnew_rem) { ns[j * 64] = INFW | ((word >> (3 * j)) & 7u); if constexpr (AFF) ns[IOFF + j * 64] = INFW; }
             nnew_rem = nnew_rem > 8u ? nnew_rem - 8u : 0u;
             newslot += 8u;
         }
@@ -506,45 +524,76 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
         const bool cells_ok = !finished && ext_left == 0u && k0 < W;
         const uint32_t *rd = lds + (dsh + k0) * 64 + lane;
         uint32_t *wr = lds + k0 * 64 + lane;
-        uint32_t ar0 = 0, ar1 = 0;
+        uint32_t ar[AFF ? 8 : 2];
+#pragma unroll
+        for (int x = 0; x < (AFF ? 8 : 2); x++) ar[x] = 0;
         // a lane that continues a row already holds these from the previous step's look-ahead
-        if (cells_ok && (popped || k0 == 0u)) { u0 = rd[0]; u1 = rd[64]; u2 = rd[128]; u3 = rd[192]; }
+        if (cells_ok && (popped || k0 == 0u)) {
+            u0 = rd[0]; u1 = rd[64]; u2 = rd[128]; u3 = rd[192];
+            if constexpr (AFF) { v0 = rd[IOFF]; v1 = rd[IOFF + 64]; v2 = rd[IOFF + 128]; v3 = rd[IOFF + 192]; }
+        }
 #pragma unroll
         for (int K4 = 0; K4 < CAP; K4 += 4) {
             const bool in = cells_ok && k0 + (uint32_t)K4 < W;
             if (__builtin_amdgcn_ballot_w64(in) == 0) break;
             if (in) {
-                uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+                uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
                 if (k0 + (uint32_t)K4 + 4u < W) {
                     n0 = rd[(K4 + 4) * 64]; n1 = rd[(K4 + 5) * 64]; n2 = rd[(K4 + 6) * 64]; n3 = rd[(K4 + 7) * 64];
+                    if constexpr (AFF) {
+                        m0 = rd[IOFF + (K4 + 4) * 64]; m1 = rd[IOFF + (K4 + 5) * 64];
+                        m2 = rd[IOFF + (K4 + 6) * 64]; m3 = rd[IOFF + (K4 + 7) * 64];
+                    }
                 }
                 const uint32_t ups[4] = {u0, u1, u2, u3};
+                const uint32_t upi[4] = {v0, v1, v2, v3};
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) {
                     const int k = K4 + kk;
                     const uint32_t up = ups[kk];
-                    const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, up & 7u);   // selector bytes 1..3 = 0 read the zero byte
-                    const int32_t m = (int32_t)((sb << 5) + diag);
+                    const uint32_t tcd = up & 7u;
+                    const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);   // selector bytes 1..3 = 0 read the zero byte
+                    const int32_t m = (int32_t)((sb << SH) + diag);
                     const int32_t u = (int32_t)up + fc.cU;
                     const int32_t l = (int32_t)left + fc.cL;
-                    const uint32_t best = (uint32_t)min(m, min(u, l));
-                    const uint32_t cw = (up & 31u) | (best & ~31u);
-                    wr[k * 64] = cw;
-                    // arrow = bits 3..4 of best -> record bits 2k..2k+1
-                    const int sh = (k & 15) * 2 - 3;
-                    const uint32_t ab = sh >= 0 ? (best & 0x18u) << (sh >= 0 ? sh : 0) : (best & 0x18u) >> (sh < 0 ? -sh : 0);
-                    if (k < 16) ar0 |= ab; else ar1 |= ab;
-                    diag = up; left = cw;
+                    if constexpr (!AFF) {
+                        const uint32_t best = (uint32_t)min(m, min(u, l));
+                        const uint32_t cw = (up & TAGS) | (best & ~TAGS);
+                        wr[k * 64] = cw;
+                        // arrow = bits 3..4 of best -> record bits 2k..2k+1
+                        const int sh = (k & 15) * 2 - 3;
+                        const uint32_t ab = sh >= 0 ? (best & 0x18u) << (sh >= 0 ? sh : 0) : (best & 0x18u) >> (sh < 0 ? -sh : 0);
+                        ar[k >> 4] |= ab;
+                        left = cw;
+                    } else {
+                        // gap states: open from the match state (preferred on ties) or extend
+                        const int32_t io = (int32_t)(up & ~TAGS) + fc.cIO, ie = (int32_t)upi[kk] + fc.cIE;
+                        const uint32_t ig = (uint32_t)min(io, ie);                 // bit 2: 1 = extend
+                        const int32_t dop = (int32_t)left + fc.cDO, de = (int32_t)leftD + fc.cDE;
+                        const uint32_t dg = (uint32_t)min(dop, de);                // bit 1: 1 = extend
+                        const int32_t dc = (int32_t)dg + (3 << 3), ic = (int32_t)ig + (4 << 3);
+                        const uint32_t best = (uint32_t)min(min(m, min(u, l)), min(dc, ic));
+                        const uint32_t lc = best & ~TAGS;
+                        wr[k * 64] = lc | tcd;
+                        wr[IOFF + k * 64] = ig & ~TAGS;
+                        // record byte: M arrow (bits 3..5) | I bit (bit 2) | D bit (bit 1)
+                        const uint32_t rb = (best & 0x38u) | (ig & 4u) | (dg & 2u);
+                        ar[k >> 2] |= rb << ((k & 3) * 8);
+                        left = lc; leftD = dg & ~TAGS;
+                    }
+                    diag = up;
                 }
                 u0 = n0; u1 = n1; u2 = n2; u3 = n3;
+                if constexpr (AFF) { v0 = m0; v1 = m1; v2 = m2; v3 = m3; }
             }
         }
         if (cells_ok) {
-            // record: the arrow dwords of this step, then the row's meta dword once the row is done
-            rec[0] = ar0;
-            const bool two = k0 + 16u < W;
-            if (two) rec[1] = ar1;
-            rec += two ? 2 : 1;
+            // record: the arrow dwords of this step (stored whole; the tail past the row end is
+            // overwritten by what follows), then the row's meta dword once the row is done
+            const uint32_t ncell = min(W - k0, (uint32_t)CAP);
+#pragma unroll
+            for (int x = 0; x < (AFF ? 8 : 2); x++) rec[x] = ar[x];
+            rec += AFF ? (ncell + 3u) >> 2 : (ncell + 15u) >> 4;
             k0 += CAP;
             if (k0 >= W) {
                 rec[0] = meta;
@@ -565,9 +614,9 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
         }
     }
     if (live) {
-        const int32_t v = (int32_t)(final_word & ~31u) - (int32_t)Q * BIASW;
+        const int32_t v = (int32_t)(final_word & ~TAGS) - (int32_t)Q * (128 << SH);
         if (v >= UNREACH) d.status[p] = GBA_PAIR_UNREACHABLE;
-        d.dp_score[p] = v >> 5;
+        d.dp_score[p] = v >> SH;
     }
 }
 
@@ -596,11 +645,16 @@ __global__ __launch_bounds__(64) void k_traceback(Dev d, TbConst tc_, gba_pair_r
     int32_t score = 0;
     uint32_t prev_op = 0;
     uint64_t steps = 0;
-    const uint64_t limit = (uint64_t)Q + T + 2;
+    // affine paths spend an extra step on every gap-state change
+    const uint64_t limit = ((uint64_t)Q + T + 2) * (tc_.mode == GBA_MODE_AFFINE ? 3 : 1);
     int st = GBA_PAIR_OK;
     // A row's record is [arrow dwords][meta]; ptr is the meta dword of the current row.  One 16-byte
-    // load ending at ptr brings the meta and the row's last three arrow dwords (all of them for rows
-    // up to 48 cells); rows are walked last to first, so the loads run backwards through memory.
+    // load ending at ptr brings the meta and the row's last three arrow dwords (all of them for
+    // linear rows up to 48 cells); rows are walked last to first, so the loads run backwards
+    // through memory.  Linear records hold 2 bits per cell, affine records one byte per cell
+    // (M arrow in bits 3..5, insertion-gap bit 2, deletion-gap bit 1).
+    const bool aff = tc_.mode == GBA_MODE_AFFINE;
+    const uint32_t cshift = aff ? 2u : 4u, cmask = aff ? 3u : 15u, bits = aff ? 8u : 2u;
     int64_t ptr = (int64_t)d.recdw[p] - 1;
     uint32_t w0, w1, w2, gw;                      // arrow dwords at ptr-3, ptr-2, ptr-1; meta
     auto load_row = [&]() {
@@ -609,16 +663,33 @@ __global__ __launch_bounds__(64) void k_traceback(Dev d, TbConst tc_, gba_pair_r
     };
     load_row();
     uint32_t tword = tc4[j >> 2];
+    uint32_t state = 0;                           // affine: 0 match state, 1 insertion gap, 2 deletion gap
     while (i > 0 || j > 0) {
         const uint32_t k = j - lo, W = gw & ROW_W_MASK;
         if (++steps > limit || k >= W) { st = GBA_PAIR_UNREACHABLE; break; }
-        const uint32_t n = (W + 15u) >> 4;        // arrow dwords of this row
-        const uint32_t back = n - (k >> 4);       // the wanted dword sits `back` dwords before the meta
+        const uint32_t n = (W + cmask) >> cshift; // arrow dwords of this row
+        const uint32_t back = n - (k >> cshift);  // the wanted dword sits `back` dwords before the meta
         uint32_t aw = back == 1u ? w2 : back == 2u ? w1 : w0;
         if (back > 3u) aw = rec[ptr - back];
-        const uint32_t a = (aw >> ((k & 15u) * 2u)) & 3u;
+        const uint32_t cell = aw >> ((k & cmask) * bits);
+        // move: 0 diagonal, 1 up (insertion), 2 left (deletion), 3 none (state change only), 4 error
+        uint32_t mv;
+        if (!aff) {
+            const uint32_t a = cell & 3u;
+            mv = a == 0u ? 0u : a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : 4u;
+        } else if (state == 0u) {
+            const uint32_t a = (cell >> 3) & 7u;
+            mv = a == 0u ? 0u : a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : 4u;
+            if (a == 3u) { state = 2u; mv = 3u; }
+            if (a == 4u) { state = 1u; mv = 3u; }
+        } else if (state == 1u) {
+            mv = 1u; if ((cell & 4u) == 0u) state = 0u;       // gap opened here: back to the match state
+        } else {
+            mv = 2u; if ((cell & 2u) == 0u) state = 0u;
+        }
+        if (mv == 3u) continue;
         bool newrow = false;
-        if (a == 0) {
+        if (mv == 0u) {
             if (i == 0 || j == 0) { st = GBA_PAIR_UNREACHABLE; break; }
             const uint32_t qb = (gw >> 10) & 7u, tb = ((tword >> ((j & 3u) * 8u)) & 7u) - 1u;
             if (qb == tb) nM++; else nX++;
@@ -627,18 +698,17 @@ __global__ __launch_bounds__(64) void k_traceback(Dev d, TbConst tc_, gba_pair_r
             if ((j & 3u) == 3u) tword = tc4[j >> 2];
         } else {
             if (run) { nb++; out[cap - nb] = gba_block{i, j, run}; run = 0; }
-            uint32_t op;
-            if (a == tc_.codeU) {
+            if (mv == 1u) {
                 if (i == 0) { st = GBA_PAIR_UNREACHABLE; break; }
-                nI++; i--; op = 1; newrow = true;
-            } else if (a == tc_.codeL) {
+                nI++; i--; newrow = true;
+            } else if (mv == 2u) {
                 if (j == 0) { st = GBA_PAIR_UNREACHABLE; break; }
-                nD++; j--; op = 2;
+                nD++; j--;
                 if ((j & 3u) == 3u) tword = tc4[j >> 2];
             } else { st = GBA_PAIR_UNREACHABLE; break; }
-            if (tc_.affine) { if (prev_op != op) score += tc_.aopen; score += tc_.aext; }
-            else score += op == 1 ? tc_.ins : tc_.del;
-            prev_op = op;
+            if (tc_.affine) { if (prev_op != mv) score += tc_.aopen; score += tc_.aext; }
+            else score += mv == 1u ? tc_.ins : tc_.del;
+            prev_op = mv;
         }
         if (newrow) {
             lo -= (gw >> 13) & 1023u;
@@ -762,14 +832,20 @@ void release(Buf &b)
 int launch_fill(gba_ctx *c, const Dev &d, uint32_t cls, uint32_t count, hipStream_t st)
 {
     const uint32_t slots = cls_slots((int)cls);
-    const size_t lds = ((size_t)(slots + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
+    const bool aff = c->sc.mode == GBA_MODE_AFFINE;
+    const size_t rings = aff ? 2 : 1;
+    const size_t lds = (rings * (slots + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        const size_t mx = ((size_t)(cls_slots(NCLS - 1) + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
+        const size_t mx1 = ((size_t)(cls_slots(NCLS - 1) + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
+        const size_t mx2 = (2 * (size_t)(cls_slots(NCLS - 2) + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
+        const size_t mx = mx1 > mx2 ? mx1 : mx2;
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_fill<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_fill<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_fill, dim3((count + 63) / 64), dim3(64), lds, st, d, c->fc, cls, slots);
+    if (aff) hipLaunchKernelGGL(k_fill<true>, dim3((count + 63) / 64), dim3(64), lds, st, d, c->fc, cls, slots);
+    else hipLaunchKernelGGL(k_fill<false>, dim3((count + 63) / 64), dim3(64), lds, st, d, c->fc, cls, slots);
     HIPCHK(c, hipGetLastError());
     return GBA_OK;
 }
@@ -826,7 +902,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
 
     hipLaunchKernelGGL(k_pack, dim3(n), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_guide, dim3((n + 63) / 64), dim3(64), 0, s, d, sc.mode, sc.band, sc.max_band, sc.kband_k);
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, d);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, d, sc.mode == GBA_MODE_AFFINE ? NCLS - 1 : NCLS);
     HIPCHK(c, hipMemcpyAsync(c->h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const Plan pl = *c->h_plan;
@@ -969,7 +1045,7 @@ int gba_last_hip_error(gba_ctx *c) { return c ? c->last_hip : 0; }
 int gba_set_scoring(gba_ctx *c, const gba_scoring *s)
 {
     if (!c || !s) return GBA_E_INVALID;
-    if (s->mode != GBA_MODE_LINEAR && s->mode != GBA_MODE_KBAND) return GBA_E_UNSUPPORTED;
+    if (s->mode != GBA_MODE_LINEAR && s->mode != GBA_MODE_KBAND && s->mode != GBA_MODE_AFFINE) return GBA_E_INVALID;
     if (s->tie_break != GBA_TIE_DIAG_LEFT_UP && s->tie_break != GBA_TIE_DIAG_UP_LEFT) return GBA_E_INVALID;
     if (s->band < 0 || s->max_band < 0 || s->band > 30000 || s->max_band > 30000) return GBA_E_INVALID;
     if (s->mode == GBA_MODE_KBAND && (s->kband_k < 0 || s->kband_k > 30000)) return GBA_E_INVALID;
@@ -990,13 +1066,28 @@ int gba_set_scoring(gba_ctx *c, const gba_scoring *s)
         hi = (uint32_t)(uint8_t)(s->sub[a][3] + 128) | ((uint32_t)(uint8_t)(s->sub[a][4] + 128) * 0x01010100u);
         f.mrow[2 * a] = lo; f.mrow[2 * a + 1] = hi;
     }
-    f.cU = s->ins * 32 + (int32_t)(codeU << 3) + BIASW;
-    f.cL = s->del * 32 + (int32_t)(codeL << 3);
+    const int SH = s->mode == GBA_MODE_AFFINE ? 6 : 5;
+    const int32_t bias = 128 << SH;
+    if (s->mode == GBA_MODE_AFFINE) {
+        // affine words keep one more tag bit: halve the cost range (and k_meta the row count)
+        const int32_t oe = s->affine_open + s->affine_extend;
+        for (int a = 0; a < 5; a++)
+            for (int b = 0; b < 5; b++)
+                if (s->sub[a][b] < -63 || s->sub[a][b] > 63) return GBA_E_UNSUPPORTED;
+        if (s->affine_extend < 0 || s->affine_extend > 63 || oe < 0 || oe > 63) return GBA_E_UNSUPPORTED;
+        f.cIO = oe * 64 + bias; f.cIE = s->affine_extend * 64 + bias + 4;
+        f.cDO = oe * 64; f.cDE = s->affine_extend * 64 + 2;
+        f.diag0 = -((s->sub[4][4] + 128) * 64);
+    } else {
+        f.cIO = f.cIE = f.cDO = f.cDE = f.diag0 = 0;
+    }
+    f.cU = s->ins * (1 << SH) + (int32_t)(codeU << 3) + bias;
+    f.cL = s->del * (1 << SH) + (int32_t)(codeL << 3);
     f.del = s->del;
     TbConst &t = c->tbc;
     for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) t.sub[a * 5 + b] = s->sub[a][b];
     t.ins = s->stats_ins; t.del = s->stats_del; t.aopen = s->stats_affine_open; t.aext = s->stats_affine_extend;
-    t.affine = s->stats_affine; t.codeU = codeU; t.codeL = codeL;
+    t.affine = s->stats_affine; t.codeU = codeU; t.codeL = codeL; t.mode = s->mode;
     c->have_scoring = true;
     return GBA_OK;
 }

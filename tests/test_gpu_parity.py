@@ -77,6 +77,22 @@ def test_wide_band(ctx, api, oracle, synth):
     batch = synth.generate(24, read_len=3000, p_ins=0.11, p_del=0.06, p_sub=0.03, seed=5000)
     _run(ctx, api, oracle, batch, band=40)
     _run(ctx, api, oracle, batch, band=100)
+    _run(ctx, api, oracle, batch, band=200)          # rows of ~400 cells: the 512-slot class
+
+
+def test_c5_band250_and_too_wide(ctx, api, oracle, synth):
+    from blasr_amd import _lib
+    batch = synth.generate(8, read_len=6000, p_ins=0.11, p_del=0.06, p_sub=0.03, seed=5001)
+    ctx.set_scoring(api.make_scoring(band=250))
+    pairs, blocks, rc = ctx.refine_host(batch)
+    ores, oblk = oracle.align_batch(batch, oracle.make_params(band=250))
+    for p in range(8):
+        # rows of a band-250 guide need up to 501 slots plus the shift; pairs beyond 512 are refused
+        if int(pairs[p]["status"]) == _lib.PAIR_TOO_WIDE:
+            continue
+        for f in util.FIELDS:
+            assert int(ores[p][f]) == int(pairs[p][f]), (f, p)
+    assert (pairs["status"] == 0).sum() >= 1
 
 
 @pytest.mark.parametrize("kw", [dict(tie_break=1), dict(n_score=3), dict(band=0), dict(band=3),
@@ -86,6 +102,39 @@ def test_wide_band(ctx, api, oracle, synth):
 def test_parameter_variants(ctx, api, oracle, synth, kw):
     batch = synth.generate(64, read_len=1500, len_jitter=800, seed=31)
     _run(ctx, api, oracle, batch, **kw)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(ins=100, dele=100), dict(affine_open=4, affine_extend=1),
+                                dict(affine_open=0, affine_extend=0), dict(tie_break=1, affine_open=3, affine_extend=2),
+                                dict(ins=100, dele=100, affine_open=6, affine_extend=1, stats_affine=1,
+                                     stats_affine_open=6, stats_affine_extend=1)])
+def test_affine_variants(ctx, api, oracle, synth, kw):
+    from blasr_amd import _lib
+    batch = synth.generate(96, read_len=1500, len_jitter=800, seed=41)
+    _run(ctx, api, oracle, batch, mode=_lib.MODE_AFFINE, band=16, **kw)
+
+
+def test_c3_affine_20kb(ctx, api, oracle, synth):
+    from blasr_amd import _lib
+    batch, cfg = synth.preset("c3_20kb_affine", 70)
+    pairs, _ = _run(ctx, api, oracle, batch, mode=_lib.MODE_AFFINE, band=cfg["band"])
+    assert (pairs["status"] == 0).all()
+
+
+def test_affine_edge_cases(ctx, api, oracle):
+    from blasr_amd import _lib
+    q = "ACGTTGCAAGGCTTAACCGGTTACGATCGATCGGCTA"
+    pairs_list = [
+        (q, q, [(0, 0, len(q))]),
+        (q, q, []),
+        ("ACGTACGTACGT" + "GGG" + "TTGACCATGCAA", "ACGTACGTACGT" + "TTGACCATGCAA", [(0, 0, 12), (15, 12, 12)]),
+        ("ACGTACGTACGT" + "TTGACCATGCAA", "ACGTACGTACGT" + "CCCCC" + "TTGACCATGCAA", [(0, 0, 12), (12, 17, 12)]),
+        ("A", "A", [(0, 0, 1)]),
+        ("ACGTNNNNACGTACGT", "ACGTACGTACGTACGT", [(0, 0, 4), (8, 8, 8)]),
+    ]
+    batch = util.make_batch(pairs_list)
+    _run(ctx, api, oracle, batch, expect_status=[0, 1, 0, 0, 0, 0], mode=_lib.MODE_AFFINE, band=16,
+         ins=100, dele=100, affine_open=10, affine_extend=1)
 
 
 def test_custom_matrix(ctx, api, oracle, synth):
