@@ -45,6 +45,7 @@ constexpr uint32_t MAX_COLS = 1u << 20;
 constexpr int NCLS = 5;                      // 32, 64, 128, 256, 512 slots (affine: up to 256, it keeps two rings)
 constexpr int PAD_SLOTS = 3;                 // a lane runs up to 3 cells past its row end (see k_fill)
 constexpr int CAP = 32;                      // cells per lane per step of k_fill
+constexpr size_t ARENA_SLACK = 256;          // bytes in front of the record / target-code arenas: k_traceback's windows start before a pair's data
 __host__ __device__ constexpr uint32_t cls_slots(int c) { return 32u << c; }
 
 // Guide stream words (one stream per pair, built by k_guide, consumed by k_fill):
@@ -238,106 +239,159 @@ __global__ __launch_bounds__(256) void k_pack(Dev d)
 // ---------------------------------------------------------------- k_guide
 // Guide rows in DP coordinates: row r covers columns [lo_r, hi_r], 0 <= lo_r <= hi_r <= T, row 0
 // is the boundary row.  A row has a centre column c and a half-width w:
-//   tPost = w, tPre = min(w, c - lo_{r-1})     (the band never reaches back past the previous row;
-//   on the first row of a block w is replaced by max_band here, so target-only gaps stay connected)
+//   hi = min(T, c + w),  lo = max(lo_{r-1}, c - w)   (the band never reaches back past the previous
+//   row; on the first row of a block w is replaced by max(max_band, w) in the lo term, so
+//   target-only gaps stay connected)
 // Inside a block c advances by one per row with w = band; between blocks the common part of the
 // gap is walked diagonally and leftover query bases repeat the column, with
 // w = min(max_band, band + |drift|).  Emits the pair's guide stream: per row one ROW word, then
 // EXT words while more than three columns enter the band on the right.
-__global__ void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
+//
+// One WAVE per pair, one LANE per row, 64 rows per iteration.  Row r of a pair lies in "unit" u =
+// the gap in front of guide block u plus block u; units tile the query, so a row finds its unit
+// from marks the unit starts leave in LDS plus a running maximum across lanes, and its centre
+// column follows in closed form from blocks u-1 and u.  lo is a running maximum of (c - w) across
+// rows, the stream offset a running sum of words per row: both are wave scans with a carry.
+constexpr int GD_WIN = 128;   // guide blocks held in LDS: blocks [wb - 1, wb + GD_WIN]
+
+__device__ __forceinline__ int32_t wave_scan_max(int32_t v)
 {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= d.n || d.status[p] != GBA_PAIR_OK) return;
-    const uint32_t Q = d.Q[p], T = d.T[p], tS = d.tS[p];
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t n = __shfl_up(v, o, 64);
+        if (lane >= o) v = max(v, n);
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_scan_sum(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(v, o, 64);
+        if (lane >= o) v += n;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
+{
+    __shared__ uint32_t mark[64];
+    __shared__ uint32_t bwin[(GD_WIN + 2) * 3];
+    const uint32_t p = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (d.status[p] != GBA_PAIR_OK) return;
+    const bool guided = mode != GBA_MODE_KBAND;
+    const uint32_t Q = d.Q[p], T = d.T[p], tS = d.tS[p], qS = d.qS[p];
     uint32_t *g = d.stream + d.word_off[p];
     const uint32_t wcap = d.wcap[p];
-    const uint32_t *qc4 = (const uint32_t *)(d.qcodes + qc_offset(d, p));    // 4 codes per dword
+    const uint8_t *qc = d.qcodes + qc_offset(d, p);
     const uint8_t *tc = d.tcodes + tc_offset(d, p);
-    const int B = mode == GBA_MODE_KBAND ? kband_k : min(band, max_band);
-    uint32_t nw = 0;                             // words produced
-    uint4 ob = make_uint4(0, 0, 0, 0);           // words are written 16 bytes at a time
-    auto push = [&](uint32_t word) {
-        const uint32_t s = nw & 3u;
-        if (s == 0) ob.x = word; else if (s == 1) ob.y = word; else if (s == 2) ob.z = word; else ob.w = word;
-        nw++;
-        if ((nw & 3u) == 0u && nw <= wcap) *(uint4 *)(g + nw - 4) = ob;
-    };
+    const uint32_t B = (uint32_t)(guided ? min(band, max_band) : kband_k);
+    const uint32_t wfirst = max((uint32_t)max_band, B);
+    const uint32_t nb = guided ? d.n_blk[p] : 0u;
+    const uint32_t *bl = (const uint32_t *)(d.blocks + (guided ? d.blk_off[p] : 0));
+    uint32_t ub = 0, wb = 0;                     // unit of the previous iteration's last row; window base
+    bool loaded = false;
+    int32_t carry_lo = 0;
+    uint32_t carry_e = 0, nw = 0;                // previous row's hi + 1; words produced
     uint64_t ncells = 0;
-    uint32_t span = 0, lo_prev = 0, Wp = 0, recdw = 0;
+    uint32_t span = 0, recdw = 0;
     bool wide = false;
-    // block state machine
-    const gba_block *bl = d.blocks + (mode == GBA_MODE_KBAND ? 0 : d.blk_off[p]);
-    uint32_t b = 0, phase = 0, remaining = 0, c = 0, w = (uint32_t)B, step = 1;
-    uint32_t bq = 0, bt = 0, blen = 0;          // current block
-    if (mode != GBA_MODE_KBAND) {
-        bq = bl[0].q_pos; bt = bl[0].t_pos; blen = bl[0].length;
-        remaining = blen; c = bt - tS; step = 1;    // c is pre-incremented below: first row centre = bt - tS + 1
-    }
-    uint32_t ins_left = 0, wgap = 0, qword = 0;
-    bool first = mode != GBA_MODE_KBAND;      // first row of a block: reaches back to the previous row's first column
-    for (uint32_t r = 0; r <= Q; r++) {
-        uint32_t lo, W, tPre;
-        if ((r & 3u) == 0u) qword = qc4[r >> 2];
-        if (r == 0) {
-            lo = 0; W = min(T, (uint32_t)B) + 1; tPre = 0; w = (uint32_t)B;
-        } else {
-            if (mode != GBA_MODE_KBAND) {
-                while (remaining == 0) {
-                    if (phase == 0) {
-                        // leaving block b: set up the gap towards block b+1
-                        const uint32_t qe = bq + blen, te = bt + blen;
-                        b++;
-                        bq = bl[b].q_pos; bt = bl[b].t_pos; blen = bl[b].length;
-                        const uint32_t qGap = bq - qe, tGap = bt - te;
-                        const int drift = (int)tGap - (int)qGap;
-                        wgap = (uint32_t)min(max_band, band + (drift < 0 ? -drift : drift));
-                        const uint32_t diag = min(qGap, tGap);
-                        ins_left = qGap - diag;
-                        phase = 1; remaining = diag; w = wgap; step = 1;
-                    } else if (phase == 1) {
-                        phase = 2; remaining = ins_left; w = wgap; step = 0;
-                    } else {
-                        phase = 0; remaining = blen; w = (uint32_t)B; step = 1; first = true;
-                        c = bt - tS;                 // jump: the next row's centre is the block's first column
-                    }
+    for (uint32_t r0 = 0; r0 <= Q; r0 += 64) {
+        const uint32_t r = r0 + lane;
+        const bool valid = r <= Q;
+        uint32_t c = r, w = B, wp = B;           // k-band: the centre is the row itself
+        if (guided) {
+            if (!loaded || ub + 64u > wb + (uint32_t)GD_WIN) {
+                __syncthreads();
+                wb = ub; loaded = true;
+                for (uint32_t k = lane; k < (uint32_t)GD_WIN + 2u; k += 64) {
+                    const uint32_t bi = wb + k - 1u;         // wraps for the slot in front of block 0
+                    if (bi < nb) { bwin[3 * k] = bl[3 * bi]; bwin[3 * k + 1] = bl[3 * bi + 1]; bwin[3 * k + 2] = bl[3 * bi + 2]; }
                 }
-                remaining--;
-            } else {
-                step = 1;
             }
-            c += step;
-            tPre = min(first ? max((uint32_t)max_band, w) : w, c - lo_prev);
-            lo = c - tPre;
-            W = min(T, c + w) - lo + 1;
-            first = false;
+            mark[lane] = 0;
+            __syncthreads();
+            {
+                // unit u starts on the row after the last row of block u - 1
+                const uint32_t u = ub + 1u + lane;
+                if (u < nb) {
+                    const uint32_t *pb = bwin + 3 * (u - wb);        // block u - 1
+                    const uint32_t rs = pb[0] + pb[2] - qS + 1u;
+                    if (rs - r0 < 64u) mark[rs - r0] = u;
+                }
+            }
+            __syncthreads();
+            const uint32_t unit = (uint32_t)max(wave_scan_max((int32_t)mark[lane]), (int32_t)ub);
+            ub = __shfl(unit, 63, 64);
+            if (valid && r > 0) {
+                const uint32_t x = r - 1u;
+                const uint32_t *cb = bwin + 3 * (unit - wb + 1u);    // block `unit`
+                const uint32_t bq = cb[0], bt = cb[1];
+                const uint32_t xb = bq - qS;
+                if (x >= xb) {
+                    c = bt - tS + 1u + (x - xb);
+                    if (x == xb) wp = wfirst;
+                } else {
+                    const uint32_t qe = cb[-3] + cb[-1], te = cb[-2] + cb[-1];   // end of block unit - 1 (unit >= 1 here)
+                    const uint32_t qGap = bq - qe, tGap = bt - te;
+                    const int drift = (int)tGap - (int)qGap;
+                    w = wp = (uint32_t)min(max_band, band + (drift < 0 ? -drift : drift));
+                    c = te - tS + min(x - (qe - qS) + 1u, min(qGap, tGap));
+                }
+            } else {
+                c = 0;
+            }
         }
-        const uint32_t dl = lo - lo_prev;
-        ncells += (uint64_t)tPre + w + 1;
-        span = max(span, dl + W);
-        recdw += 1u + (mode == GBA_MODE_AFFINE ? (W + 3u) >> 2 : (W + 15u) >> 4);
-        if (dl > 1023u || W > 1023u) wide = true;
-        // columns entering on the right: (hi_prev, hi] = lo_prev + Wp .. lo + W - 1
-        const uint32_t cnew = lo_prev + Wp;
-        const uint32_t nnew = dl + W > Wp ? dl + W - Wp : 0;
-        const uint32_t qcode = (qword >> ((r & 3u) * 8u)) & 7u;
-        uint32_t word = (W & ROW_W_MASK) | (qcode << 10) | ((dl & 1023u) << 13);
-        for (uint32_t j = 0; j < 3 && j < nnew; j++) word |= (uint32_t)tc[cnew + j] << (23 + 3 * j);
-        push(word);
-        for (uint32_t j = 3; j < nnew; j += 8) {
-            uint32_t e = 0;
-            for (uint32_t x = 0; x < 8 && j + x < nnew; x++) e |= (uint32_t)tc[cnew + j + x] << (3 * x);
-            push(e);
+        const int32_t cand = valid ? (int32_t)c - (int32_t)wp : (int32_t)0x80000000;
+        const uint32_t lo = (uint32_t)max(wave_scan_max(cand), carry_lo);
+        const uint32_t e = min(T, c + w) + 1u;   // hi + 1
+        uint32_t lo_prev = __shfl_up(lo, 1, 64), e_prev = __shfl_up(e, 1, 64);
+        if (lane == 0) { lo_prev = (uint32_t)carry_lo; e_prev = carry_e; }
+        carry_lo = (int32_t)__shfl(lo, 63, 64); carry_e = __shfl(e, 63, 64);
+        const uint32_t W = e - lo, dl = lo - lo_prev;
+        // columns entering on the right: [hi_prev + 1, hi]
+        const uint32_t nnew = valid && e > e_prev ? e - e_prev : 0u, cnew = e_prev;
+        const uint32_t words = valid ? 1u + (nnew > 3u ? (nnew + 4u) >> 3 : 0u) : 0u;
+        const uint32_t incl = wave_scan_sum(words);
+        const uint32_t off = nw + incl - words;
+        nw += __shfl(incl, 63, 64);
+        if (valid) {
+            ncells += (uint64_t)(c - lo) + w + 1u;
+            span = max(span, dl + W);
+            recdw += 1u + (mode == GBA_MODE_AFFINE ? (W + 3u) >> 2 : (W + 15u) >> 4);
+            if (dl > 1023u || W > 1023u) wide = true;
+            uint32_t word = (W & ROW_W_MASK) | ((uint32_t)qc[r] << 10) | ((dl & 1023u) << 13);
+            if (nnew > 0u) word |= (uint32_t)tc[cnew] << 23;
+            if (nnew > 1u) word |= (uint32_t)tc[cnew + 1u] << 26;
+            if (nnew > 2u) word |= (uint32_t)tc[cnew + 2u] << 29;
+            if (off < wcap) g[off] = word;
+            uint32_t o = off + 1u;
+            for (uint32_t j = 3; j < nnew; j += 8, o++) {
+                uint32_t ew = 0;
+                for (uint32_t x = 0; x < 8 && j + x < nnew; x++) ew |= (uint32_t)tc[cnew + j + x] << (3 * x);
+                if (o < wcap) g[o] = ew;
+            }
+            if (r == Q) d.lo_last[p] = lo;
         }
-        lo_prev = lo; Wp = W;
     }
-    if (nw + 8 > wcap) wide = true;              // cannot happen (see k_meta); never overrun the stream
-    // flush the partial group and zero the rest of the pair's stream (whole 4-word groups)
-    const uint32_t nreal = nw;
-    while ((nw & 3u) != 0u) push(0);
-    (void)nreal;
-    for (uint32_t x = nw; x + 4 <= wcap; x += 4) *(uint4 *)(g + x) = make_uint4(0, 0, 0, 0);
-    d.span[p] = span; d.ncells[p] = ncells; d.lo_last[p] = lo_prev; d.recdw[p] = recdw;
-    if (wide) d.status[p] = GBA_PAIR_TOO_WIDE;
+    // totals of the pair
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ncells += __shfl_xor((unsigned long long)ncells, o, 64);
+        recdw += __shfl_xor(recdw, o, 64);
+        span = max(span, __shfl_xor(span, o, 64));
+    }
+    wide = __any(wide) || nw + 8u > wcap;        // the second cannot happen (see k_meta); never overrun the stream
+    // k_fill fetches whole 4-word groups a little past the last word
+    for (uint32_t x = nw + lane; x < wcap && x < nw + 24u; x += 64) g[x] = 0;
+    if (lane == 0) {
+        d.span[p] = span; d.ncells[p] = ncells; d.recdw[p] = recdw;
+        if (wide) d.status[p] = GBA_PAIR_TOO_WIDE;
+    }
 }
 
 // ---------------------------------------------------------------- k_plan
@@ -625,16 +679,28 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
 // into blocks (ArrowPathToAlignment), count matches / mismatches / gaps and rescore the path
 // (ComputeAlignmentStats).  Blocks are produced last-to-first, so they are written from the end
 // of the pair's scratch region backwards and come out in forward order.
+//
+// A row's record is [arrow dwords][meta]; rows are walked last to first, so a lane reads its
+// record array backwards.  Every lane keeps the TB_RW record dwords that end at its position and
+// TB_TW dwords of target codes in an LDS window ([dword][lane]).  A dependent global load per row
+// would cost a full memory round trip per row; instead ALL lanes of the wave refill their windows
+// together whenever any lane is about to leave its window, one round trip per ~20 rows.
+constexpr int TB_RW = 64, TB_TW = 16;
+typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
 __global__ __launch_bounds__(64) void k_traceback(Dev d, TbConst tc_, gba_pair_result *res)
 {
     __shared__ int32_t sub[25];
+    __shared__ uint32_t rwin[TB_RW * 64];
+    __shared__ uint32_t twin[TB_TW * 64];
     if (threadIdx.x < 25) sub[threadIdx.x] = tc_.sub[threadIdx.x];
     __syncthreads();
+    const int lane = threadIdx.x;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= d.plan->n_ok) return;
-    const uint32_t p = d.order[idx];
-    gba_pair_result &R = res[p];
-    if (d.status[p] != GBA_PAIR_OK) return;      // fill found the end cell unreachable
+    const uint32_t n_ok = d.plan->n_ok;
+    if (blockIdx.x * blockDim.x >= n_ok) return;
+    const uint32_t p = d.order[idx < n_ok ? idx : n_ok - 1];
+    const bool live = idx < n_ok && d.status[p] == GBA_PAIR_OK;   // else: fill found the end cell unreachable
     const uint32_t Q = d.Q[p], T = d.T[p];
     const uint32_t *rec = d.rec + d.rec_off[p];
     const uint32_t *tc4 = (const uint32_t *)(d.tcodes + tc_offset(d, p));   // 4 column codes per dword
@@ -648,29 +714,54 @@ __global__ __launch_bounds__(64) void k_traceback(Dev d, TbConst tc_, gba_pair_r
     // affine paths spend an extra step on every gap-state change
     const uint64_t limit = ((uint64_t)Q + T + 2) * (tc_.mode == GBA_MODE_AFFINE ? 3 : 1);
     int st = GBA_PAIR_OK;
-    // A row's record is [arrow dwords][meta]; ptr is the meta dword of the current row.  One 16-byte
-    // load ending at ptr brings the meta and the row's last three arrow dwords (all of them for
-    // linear rows up to 48 cells); rows are walked last to first, so the loads run backwards
-    // through memory.  Linear records hold 2 bits per cell, affine records one byte per cell
-    // (M arrow in bits 3..5, insertion-gap bit 2, deletion-gap bit 1).
+    // Linear records hold 2 bits per cell, affine records one byte per cell (M arrow in bits
+    // 3..5, insertion-gap bit 2, deletion-gap bit 1).
     const bool aff = tc_.mode == GBA_MODE_AFFINE;
     const uint32_t cshift = aff ? 2u : 4u, cmask = aff ? 3u : 15u, bits = aff ? 8u : 2u;
-    int64_t ptr = (int64_t)d.recdw[p] - 1;
-    uint32_t w0, w1, w2, gw;                      // arrow dwords at ptr-3, ptr-2, ptr-1; meta
-    auto load_row = [&]() {
-        const uint32_t *q = rec + ptr - 3;
-        w0 = q[0]; w1 = q[1]; w2 = q[2]; gw = q[3];
-    };
-    load_row();
-    uint32_t tword = tc4[j >> 2];
+    int32_t ptr = (int32_t)d.recdw[p] - 1;        // meta dword of the current row
+    int32_t rb = 0x7fffffff, tb = 0x7fffffff;     // first record dword / code dword held in the windows
+    auto rd_rec = [&](int32_t x) -> uint32_t { return x >= rb ? rwin[(x - rb) * 64 + lane] : rec[x]; };
+    auto rd_tc = [&](int32_t x) -> uint32_t { return x >= tb ? twin[(x - tb) * 64 + lane] : tc4[x]; };
+    uint32_t gw = live ? rec[ptr] : 0u;
+    uint32_t tword = live ? tc4[j >> 2] : 0u;
     uint32_t state = 0;                           // affine: 0 match state, 1 insertion gap, 2 deletion gap
-    while (i > 0 || j > 0) {
-        const uint32_t k = j - lo, W = gw & ROW_W_MASK;
-        if (++steps > limit || k >= W) { st = GBA_PAIR_UNREACHABLE; break; }
+    for (;;) {
+        const bool active = live && st == GBA_PAIR_OK && (i > 0 || j > 0);
+        if (!__any(active)) break;
+        const uint32_t W = gw & ROW_W_MASK;
         const uint32_t n = (W + cmask) >> cshift; // arrow dwords of this row
+        {
+            const int32_t look = (int32_t)min(n + 1u, (uint32_t)TB_RW - 1u);
+            if (__any(active && ptr - look < rb)) {
+                if (active) {
+                    rb = ptr - (TB_RW - 1);
+                    const uint32_t *src = rec + rb;
+#pragma unroll
+                    for (int c = 0; c < TB_RW / 4; c++) {
+                        const u32x4u v = *(const u32x4u *)(src + 4 * c);
+                        uint32_t *w = rwin + (4 * c) * 64 + lane;
+                        w[0] = v.x; w[64] = v.y; w[128] = v.z; w[192] = v.w;
+                    }
+                }
+            }
+            if (__any(active && (int32_t)(j >> 2) - 1 < tb)) {
+                if (active) {
+                    tb = (int32_t)(j >> 2) - (TB_TW - 1);
+                    const uint32_t *src = tc4 + tb;
+#pragma unroll
+                    for (int c = 0; c < TB_TW / 4; c++) {
+                        const u32x4u v = *(const u32x4u *)(src + 4 * c);
+                        uint32_t *w = twin + (4 * c) * 64 + lane;
+                        w[0] = v.x; w[64] = v.y; w[128] = v.z; w[192] = v.w;
+                    }
+                }
+            }
+        }
+        if (!active) continue;
+        const uint32_t k = j - lo;
+        if (++steps > limit || k >= W) { st = GBA_PAIR_UNREACHABLE; continue; }
         const uint32_t back = n - (k >> cshift);  // the wanted dword sits `back` dwords before the meta
-        uint32_t aw = back == 1u ? w2 : back == 2u ? w1 : w0;
-        if (back > 3u) aw = rec[ptr - back];
+        const uint32_t aw = rd_rec(ptr - (int32_t)back);
         const uint32_t cell = aw >> ((k & cmask) * bits);
         // move: 0 diagonal, 1 up (insertion), 2 left (deletion), 3 none (state change only), 4 error
         uint32_t mv;
@@ -690,32 +781,34 @@ __global__ __launch_bounds__(64) void k_traceback(Dev d, TbConst tc_, gba_pair_r
         if (mv == 3u) continue;
         bool newrow = false;
         if (mv == 0u) {
-            if (i == 0 || j == 0) { st = GBA_PAIR_UNREACHABLE; break; }
-            const uint32_t qb = (gw >> 10) & 7u, tb = ((tword >> ((j & 3u) * 8u)) & 7u) - 1u;
-            if (qb == tb) nM++; else nX++;
-            score += sub[qb * 5 + tb];
+            if (i == 0 || j == 0) { st = GBA_PAIR_UNREACHABLE; continue; }
+            const uint32_t qb = (gw >> 10) & 7u, tbase = ((tword >> ((j & 3u) * 8u)) & 7u) - 1u;
+            if (qb == tbase) nM++; else nX++;
+            score += sub[qb * 5 + tbase];
             run++; i--; j--; prev_op = 0; newrow = true;
-            if ((j & 3u) == 3u) tword = tc4[j >> 2];
+            if ((j & 3u) == 3u) tword = rd_tc((int32_t)(j >> 2));
         } else {
             if (run) { nb++; out[cap - nb] = gba_block{i, j, run}; run = 0; }
             if (mv == 1u) {
-                if (i == 0) { st = GBA_PAIR_UNREACHABLE; break; }
+                if (i == 0) { st = GBA_PAIR_UNREACHABLE; continue; }
                 nI++; i--; newrow = true;
             } else if (mv == 2u) {
-                if (j == 0) { st = GBA_PAIR_UNREACHABLE; break; }
+                if (j == 0) { st = GBA_PAIR_UNREACHABLE; continue; }
                 nD++; j--;
-                if ((j & 3u) == 3u) tword = tc4[j >> 2];
-            } else { st = GBA_PAIR_UNREACHABLE; break; }
+                if ((j & 3u) == 3u) tword = rd_tc((int32_t)(j >> 2));
+            } else { st = GBA_PAIR_UNREACHABLE; continue; }
             if (tc_.affine) { if (prev_op != mv) score += tc_.aopen; score += tc_.aext; }
             else score += mv == 1u ? tc_.ins : tc_.del;
             prev_op = mv;
         }
         if (newrow) {
             lo -= (gw >> 13) & 1023u;
-            ptr -= (int64_t)n + 1;
-            load_row();
+            ptr -= (int32_t)n + 1;
+            gw = rd_rec(ptr);
         }
     }
+    if (!live) return;
+    gba_pair_result &R = res[p];
     if (run) { nb++; out[cap - nb] = gba_block{i, j, run}; }
     if (st != GBA_PAIR_OK) { d.status[p] = st; nb = 0; }
     R.n_blk = nb; R.score = score;
@@ -894,20 +987,20 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     const uint64_t rows = c->h_plan->total_rows, cols = c->h_plan->total_cols;
     { int rc = ensure(c, c->b_guide, (size_t)(c->h_plan->total_words + 16) * 4); if (rc) return rc; }
     { int rc = ensure(c, c->b_qc, (size_t)(rows + 32ull * n + 64)); if (rc) return rc; }
-    { int rc = ensure(c, c->b_tc, (size_t)(cols + 32ull * n + 64)); if (rc) return rc; }
+    { int rc = ensure(c, c->b_tc, (size_t)(cols + 32ull * n + 64 + 2 * ARENA_SLACK)); if (rc) return rc; }
     { int rc = ensure(c, c->b_blk, (size_t)(rows + 4) * sizeof(gba_block)); if (rc) return rc; }
     d.stream = (uint32_t *)c->b_guide.ptr;
-    d.qcodes = (uint8_t *)c->b_qc.ptr; d.tcodes = (uint8_t *)c->b_tc.ptr;
+    d.qcodes = (uint8_t *)c->b_qc.ptr; d.tcodes = (uint8_t *)c->b_tc.ptr + ARENA_SLACK;
     d.blk_scratch = (gba_block *)c->b_blk.ptr;
 
     hipLaunchKernelGGL(k_pack, dim3(n), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(k_guide, dim3((n + 63) / 64), dim3(64), 0, s, d, sc.mode, sc.band, sc.max_band, sc.kband_k);
+    hipLaunchKernelGGL(k_guide, dim3(n), dim3(64), 0, s, d, sc.mode, sc.band, sc.max_band, sc.kband_k);
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, d, sc.mode == GBA_MODE_AFFINE ? NCLS - 1 : NCLS);
     HIPCHK(c, hipMemcpyAsync(c->h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const Plan pl = *c->h_plan;
-    { int rc = ensure(c, c->b_rec, (size_t)(pl.total_rec_dwords + 16) * 4); if (rc) return rc; }
-    d.rec = (uint32_t *)c->b_rec.ptr;
+    { int rc = ensure(c, c->b_rec, (size_t)(pl.total_rec_dwords + 16) * 4 + ARENA_SLACK); if (rc) return rc; }
+    d.rec = (uint32_t *)((uint8_t *)c->b_rec.ptr + ARENA_SLACK);
 
     gba_pair_result *res = out->pairs;
     hipLaunchKernelGGL(k_results_init, dim3(g256), dim3(256), 0, s, d, res);
