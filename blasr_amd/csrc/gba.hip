@@ -34,6 +34,10 @@
 
 namespace {
 
+// vectors that are only dword aligned (per-lane positions in dword streams)
+typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2u __attribute__((ext_vector_type(2), aligned(4)));
+
 constexpr uint32_t INFW = 0x40000000u;       // "no path" cell word
 constexpr int32_t UNREACH = 0x20000000;      // unbiased words at or above this are unreachable
 constexpr int32_t BIASW = 128 << 5;          // per-row bias of the byte substitution table
@@ -43,7 +47,8 @@ constexpr uint32_t MAX_COLS = 1u << 20;
 // Classes of the lane-per-pair fill kernel: a pair's class is the smallest LDS row buffer
 // (32 << class slots) that holds its widest "shift + width".  Each non-empty class is one launch.
 constexpr int NCLS = 5;                      // 32, 64, 128, 256, 512 slots (affine: up to 256, it keeps two rings)
-constexpr int PAD_SLOTS = 3;                 // a lane runs up to 3 cells past its row end (see k_fill)
+constexpr int PAD_SLOTS = 3;                 // spare slots behind a ring
+constexpr int SPAN_MARGIN = 4;               // a pair fits a class if its widest shift + width <= slots - SPAN_MARGIN (k_fill touches up to 7 slots past a row end)
 constexpr int CAP = 32;                      // cells per lane per step of k_fill
 constexpr size_t ARENA_SLACK = 256;          // bytes in front of the record / target-code arenas: k_traceback's windows start before a pair's data
 __host__ __device__ constexpr uint32_t cls_slots(int c) { return 32u << c; }
@@ -254,26 +259,43 @@ __global__ __launch_bounds__(256) void k_pack(Dev d)
 // rows, the stream offset a running sum of words per row: both are wave scans with a carry.
 constexpr int GD_WIN = 128;   // guide blocks held in LDS: blocks [wb - 1, wb + GD_WIN]
 
+// Inclusive wave scans through DPP row shifts and row broadcasts (no LDS traffic).  Lanes whose
+// source lies outside the row / the written rows receive the identity.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int32_t dpp_from(int32_t identity, int32_t v)
+{
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+
 __device__ __forceinline__ int32_t wave_scan_max(int32_t v)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int32_t n = __shfl_up(v, o, 64);
-        if (lane >= o) v = max(v, n);
-    }
+    constexpr int32_t ID = (int32_t)0x80000000;
+    v = max(v, dpp_from<0x111, 0xf>(ID, v));     // row_shr:1
+    v = max(v, dpp_from<0x112, 0xf>(ID, v));     // row_shr:2
+    v = max(v, dpp_from<0x114, 0xf>(ID, v));     // row_shr:4
+    v = max(v, dpp_from<0x118, 0xf>(ID, v));     // row_shr:8
+    v = max(v, dpp_from<0x142, 0xa>(ID, v));     // row_bcast:15 into rows 1 and 3
+    v = max(v, dpp_from<0x143, 0xc>(ID, v));     // row_bcast:31 into rows 2 and 3
     return v;
 }
 
-__device__ __forceinline__ uint32_t wave_scan_sum(uint32_t v)
+__device__ __forceinline__ uint32_t wave_scan_sum(uint32_t u)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t n = __shfl_up(v, o, 64);
-        if (lane >= o) v += n;
-    }
-    return v;
+    int32_t v = (int32_t)u;
+    v += dpp_from<0x111, 0xf>(0, v);
+    v += dpp_from<0x112, 0xf>(0, v);
+    v += dpp_from<0x114, 0xf>(0, v);
+    v += dpp_from<0x118, 0xf>(0, v);
+    v += dpp_from<0x142, 0xa>(0, v);
+    v += dpp_from<0x143, 0xc>(0, v);
+    return (uint32_t)v;
+}
+
+// value of the previous lane (lane 0 receives `first`)
+__device__ __forceinline__ uint32_t wave_prev(uint32_t v, uint32_t first)
+{
+    // wave_shr:1 shifts across the whole wave
+    return (uint32_t)__builtin_amdgcn_update_dpp((int32_t)first, (int32_t)v, 0x138, 0xf, 0xf, false);
 }
 
 __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
@@ -326,7 +348,7 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
             }
             __syncthreads();
             const uint32_t unit = (uint32_t)max(wave_scan_max((int32_t)mark[lane]), (int32_t)ub);
-            ub = __shfl(unit, 63, 64);
+            ub = (uint32_t)__builtin_amdgcn_readlane((int32_t)unit, 63);
             if (valid && r > 0) {
                 const uint32_t x = r - 1u;
                 const uint32_t *cb = bwin + 3 * (unit - wb + 1u);    // block `unit`
@@ -349,16 +371,15 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
         const int32_t cand = valid ? (int32_t)c - (int32_t)wp : (int32_t)0x80000000;
         const uint32_t lo = (uint32_t)max(wave_scan_max(cand), carry_lo);
         const uint32_t e = min(T, c + w) + 1u;   // hi + 1
-        uint32_t lo_prev = __shfl_up(lo, 1, 64), e_prev = __shfl_up(e, 1, 64);
-        if (lane == 0) { lo_prev = (uint32_t)carry_lo; e_prev = carry_e; }
-        carry_lo = (int32_t)__shfl(lo, 63, 64); carry_e = __shfl(e, 63, 64);
+        const uint32_t lo_prev = wave_prev(lo, (uint32_t)carry_lo), e_prev = wave_prev(e, carry_e);
+        carry_lo = (int32_t)__builtin_amdgcn_readlane((int32_t)lo, 63); carry_e = (uint32_t)__builtin_amdgcn_readlane((int32_t)e, 63);
         const uint32_t W = e - lo, dl = lo - lo_prev;
         // columns entering on the right: [hi_prev + 1, hi]
         const uint32_t nnew = valid && e > e_prev ? e - e_prev : 0u, cnew = e_prev;
         const uint32_t words = valid ? 1u + (nnew > 3u ? (nnew + 4u) >> 3 : 0u) : 0u;
         const uint32_t incl = wave_scan_sum(words);
         const uint32_t off = nw + incl - words;
-        nw += __shfl(incl, 63, 64);
+        nw += (uint32_t)__builtin_amdgcn_readlane((int32_t)incl, 63);
         if (valid) {
             ncells += (uint64_t)(c - lo) + w + 1u;
             span = max(span, dl + W);
@@ -408,7 +429,7 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls)
         uint32_t c = NCLS;
         if (d.status[p] == GBA_PAIR_OK) {
             const uint32_t s = d.span[p];
-            for (int k = ncls - 1; k >= 0; k--) if (s <= cls_slots(k)) c = (uint32_t)k;
+            for (int k = ncls - 1; k >= 0; k--) if (s + SPAN_MARGIN <= cls_slots(k)) c = (uint32_t)k;
             if (c == NCLS) d.status[p] = GBA_PAIR_TOO_WIDE;
             else atomicAdd(&cnt[c], 1u);
         }
@@ -449,8 +470,8 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls)
 // One LANE per pair, 64 pairs per wave.  Lanes are NOT in row lock step: every lane walks its own
 // guide stream.  One step of the (wave-uniform) loop lets each lane
 //   1. if its current row is finished, pop the next ROW word: new width / shift / query base,
-//      write the INFW words of up to three entering columns; or, if the row still has entering
-//      columns pending, pop an EXT word and write up to eight more;
+//      write the INFW words of three entering columns; or, if the row still has entering columns
+//      pending, pop an EXT word and write eight more;
 //   2. compute up to CAP cells of its current row (rows wider than CAP continue next step).
 // A lane with a 21-cell row and a lane with a 60-cell row therefore cost 2 and 4 steps, instead of
 // both paying for the widest row of the wave.
@@ -459,8 +480,10 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls)
 // free whatever the per-lane slot).  Slots are RELATIVE to the row's first column: cell k of a row
 // reads its vertical predecessor from slot k + shift (the previous row's layout) and overwrites
 // slot k; the read of a slot always precedes the write that destroys it, so one row buffer is
-// enough.  Inside a step a lane runs whole groups of 4 cells, up to 3 cells past its row end;
-// those cells only touch slots below slots + PAD_SLOTS and record bits nobody reads.
+// enough.  Slots at and right of shift + width hold nothing a valid cell reads: the entering-column
+// writes and the cell groups run unmasked past the row end (whole groups of 8 cells, whole words
+// of 3 / 8 entering columns), which is why a pair's widest shift + width must stay SPAN_MARGIN
+// below the ring size.
 //
 // Guide words arrive through a 12-word LDS ring per lane, refilled every 4th step with a 4-word
 // group that is requested at the start of that step and installed at its end; that wait is the
@@ -476,13 +499,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <bool AFF>
 __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, uint32_t slots)
 {
-    extern __shared__ uint32_t lds[];
+    extern __shared__ uint32_t smem[];
     constexpr int SH = AFF ? 6 : 5;                     // score shift of a cell word
     constexpr uint32_t TAGS = (1u << SH) - 1u;
+    constexpr int NAR = AFF ? 8 : 2;                    // record dwords of one step
     const int lane = threadIdx.x;
     const uint32_t SL = slots + PAD_SLOTS;              // slots of one ring
-    uint32_t *tab = lds + (AFF ? 2u : 1u) * SL * 64;
-    uint32_t *fifo = tab + LDS_TAB;
+    uint32_t *tab = smem, *fifo = smem + LDS_TAB, *lds = smem + LDS_TAB + LDS_FIFO;
+    const uint32_t IOFF = SL * 64;                      // dword offset of the I ring
     if (lane < 10) tab[lane] = fc.mrow[lane];
     __syncthreads();
     const uint32_t cnt = d.plan->cls_count[cls], cbase = d.plan->cls_base[cls];
@@ -490,11 +514,15 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     if (blockIdx.x * 64 >= cnt) return;
     const bool live = idx < cnt;
     const uint32_t p = d.order[cbase + (live ? idx : cnt - 1)];
-    const uint32_t Q = d.Q[p], T = d.T[p];
+    const uint32_t Q = d.Q[p];
+    const uint32_t fslot = d.T[p] - d.lo_last[p];       // slot of the end cell (Q, T) in the last row
     const uint32_t *st = d.stream + d.word_off[p];
     const uint32_t wcap = d.wcap[p];
-    uint32_t *rec = d.rec + d.rec_off[p];               // next record dword of this pair
-    const uint32_t IOFF = SL * 64;                      // dword offset of the I ring
+    // record stores: a wave-uniform base (the wave's first pair has the lowest offset, pairs of a
+    // class are ordered by index) plus a 32-bit byte offset per lane
+    const uint64_t rbase = d.rec_off[d.order[cbase + blockIdx.x * 64]];
+    char *recb = (char *)(d.rec + rbase);
+    uint32_t rob = (uint32_t)(d.rec_off[p] - rbase) * 4u;
 
     // FIFO: stream words [wc, wi) are in the LDS ring; hs / is are the ring slots of words wc / wi.
     // At least two words are buffered at the start of every step (see the refill rule below), so
@@ -508,16 +536,14 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     }
 
     uint32_t rows_left = live ? Q + 1 : 0;              // rows not yet started
-    uint32_t W = 0, dsh = 0, k0 = 0, Wp = 0, lo = 0;    // current row: width, shift, cells done; previous width, first column
-    uint32_t ext_left = 0, nnew_rem = 0, newslot = 0;
+    uint32_t W = 0, dsh = 0, k0 = 0, Wp = 0;            // current row: width, shift, cells done; previous width
+    uint32_t ext_left = 0, newslot = 0;
     uint32_t diag = INFW, left = INFW, leftD = INFW, mlo = 0, mhi = 0, meta = 0;
     bool first = true, finished = !live;
     uint32_t final_word = INFW;
     // the next word of the stream and the matrix row of its query base are fetched one step ahead
     uint32_t nword = fifo[lane];                       // ring slot hs = 0
     uint32_t nmlo = tab[((nword >> 10) & 7u) * 2], nmhi = tab[((nword >> 10) & 7u) * 2 + 1];
-    uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0;            // vertical predecessors (M) of the next 4 cells
-    uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;            // vertical predecessors (I), affine only
 
     for (uint32_t it = 0; __any(!finished); it++) {
         // Refill (every 4th step): a lane with at most 8 of its 12 ring words left requests the next
@@ -533,27 +559,26 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
             }
         }
         // ---- 1. word pop
-        const bool inrow = k0 < W;
-        const bool pop_row = !finished && !inrow && ext_left == 0u && rows_left > 0u;
         const bool pop_ext = !finished && ext_left > 0u;
+        const bool pop_row = !finished && ext_left == 0u && k0 >= W && rows_left > 0u;
         const uint32_t word = nword;
         if (pop_row) {
-            wc++; hs = hs == FIFO_WORDS - 1 ? 0u : hs + 1u; rows_left--;
-            lo += dsh; Wp = W;
+            rows_left--;
+            Wp = W;
             W = word & ROW_W_MASK; dsh = (word >> 13) & 1023u;
             mlo = nmlo; mhi = nmhi;
             const uint32_t tot = dsh + W;
-            nnew_rem = tot > Wp ? tot - Wp : 0u;
+            const uint32_t nnew = tot > Wp ? tot - Wp : 0u;
             uint32_t *ns = lds + Wp * 64 + lane;
-            if (nnew_rem > 0u) { ns[0] = INFW | ((word >> 23) & 7u); if constexpr (AFF) ns[IOFF] = INFW; }
-            if (nnew_rem > 1u) { ns[64] = INFW | ((word >> 26) & 7u); if constexpr (AFF) ns[IOFF + 64] = INFW; }
-            if (nnew_rem > 2u) { ns[128] = INFW | (word >> 29); if constexpr (AFF) ns[IOFF + 128] = INFW; }
-            nnew_rem = nnew_rem > 3u ? nnew_rem - 3u : 0u;
-            ext_left = (nnew_rem + 7u) >> 3;
+            ns[0] = INFW | ((word >> 23) & 7u); ns[64] = INFW | ((word >> 26) & 7u); ns[128] = INFW | (word >> 29);
+            if constexpr (AFF) { ns[IOFF] = INFW; ns[IOFF + 64] = INFW; ns[IOFF + 128] = INFW; }
+            ext_left = nnew > 3u ? (nnew + 4u) >> 3 : 0u;
             newslot = Wp + 3u;
             k0 = 0;
-            diag = INFW; left = INFW; leftD = INFW;
-            if (dsh >= 1u && dsh - 1u < Wp) diag = lds[(dsh - 1u) * 64 + lane];
+            // the diagonal predecessor of the row's first cell (INFW when it lies outside the previous row)
+            const uint32_t dv = lds[(max(dsh, 1u) - 1u) * 64 + lane];
+            diag = dsh - 1u < Wp ? dv : INFW;
+            left = INFW; leftD = INFW;
             if (first) {
                 // row 0: linear starts from "one deletion before column 0" so that cell j costs j
                 // deletions; affine makes the diagonal candidate of cell (0,0) cost exactly 0
@@ -561,99 +586,96 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
             }
             first = false;
             meta = word & ROW_META_MASK;
-        } else if (pop_ext) {
-            wc++; hs = hs == FIFO_WORDS - 1 ? 0u : hs + 1u; ext_left--;
+        }
+        if (pop_ext) {
+            ext_left--;
             uint32_t *ns = lds + newslot * 64 + lane;
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                if ((uint32_t)j < nnew_rem) { ns[j * 64] = INFW | ((word >> (3 * j)) & 7u); if constexpr (AFF) ns[IOFF + j * 64] = INFW; }
-            nnew_rem = nnew_rem > 8u ? nnew_rem - 8u : 0u;
+            for (int j = 0; j < 8; j++) {
+                ns[j * 64] = INFW | ((word >> (3 * j)) & 7u);
+                if constexpr (AFF) ns[IOFF + j * 64] = INFW;
+            }
             newslot += 8u;
         }
-        const bool popped = pop_row || pop_ext;
+        if (pop_row || pop_ext) { wc++; hs = hs == FIFO_WORDS - 1 ? 0u : hs + 1u; }
         // peek the following word (not needed before the next step)
         nword = fifo[hs * 64 + lane];
         nmlo = tab[((nword >> 10) & 7u) * 2]; nmhi = tab[((nword >> 10) & 7u) * 2 + 1];
-        // ---- 2. up to CAP cells of the current row
-        const bool cells_ok = !finished && ext_left == 0u && k0 < W;
-        const uint32_t *rd = lds + (dsh + k0) * 64 + lane;
-        uint32_t *wr = lds + k0 * 64 + lane;
-        uint32_t ar[AFF ? 8 : 2];
+        // ---- 2. up to CAP cells of the current row, in groups of 8
+        if (!finished && ext_left == 0u && k0 < W) {
+            const uint32_t *rd = lds + (dsh + k0) * 64 + lane;
+            uint32_t *wr = lds + k0 * 64 + lane;
+            const uint32_t rem = W - k0;
+            uint32_t ar[NAR];
 #pragma unroll
-        for (int x = 0; x < (AFF ? 8 : 2); x++) ar[x] = 0;
-        // a lane that continues a row already holds these from the previous step's look-ahead
-        if (cells_ok && (popped || k0 == 0u)) {
-            u0 = rd[0]; u1 = rd[64]; u2 = rd[128]; u3 = rd[192];
-            if constexpr (AFF) { v0 = rd[IOFF]; v1 = rd[IOFF + 64]; v2 = rd[IOFF + 128]; v3 = rd[IOFF + 192]; }
-        }
+            for (int x = 0; x < NAR; x++) ar[x] = 0;
+            uint32_t up[2][8], ui[2][8];
 #pragma unroll
-        for (int K4 = 0; K4 < CAP; K4 += 4) {
-            const bool in = cells_ok && k0 + (uint32_t)K4 < W;
-            if (__builtin_amdgcn_ballot_w64(in) == 0) break;
-            if (in) {
-                uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-                if (k0 + (uint32_t)K4 + 4u < W) {
-                    n0 = rd[(K4 + 4) * 64]; n1 = rd[(K4 + 5) * 64]; n2 = rd[(K4 + 6) * 64]; n3 = rd[(K4 + 7) * 64];
-                    if constexpr (AFF) {
-                        m0 = rd[IOFF + (K4 + 4) * 64]; m1 = rd[IOFF + (K4 + 5) * 64];
-                        m2 = rd[IOFF + (K4 + 6) * 64]; m3 = rd[IOFF + (K4 + 7) * 64];
+            for (int x = 0; x < 8; x++) { up[0][x] = rd[x * 64]; if constexpr (AFF) ui[0][x] = rd[IOFF + x * 64]; }
+#pragma unroll
+            for (int G = 0; G < CAP / 8; G++) {
+                if (rem > (uint32_t)(8 * G)) {
+                    if (G + 1 < CAP / 8 && rem > (uint32_t)(8 * G + 8)) {
+#pragma unroll
+                        for (int x = 0; x < 8; x++) {
+                            up[(G + 1) & 1][x] = rd[(8 * G + 8 + x) * 64];
+                            if constexpr (AFF) ui[(G + 1) & 1][x] = rd[IOFF + (8 * G + 8 + x) * 64];
+                        }
+                    }
+#pragma unroll
+                    for (int x = 0; x < 8; x++) {
+                        const int k = 8 * G + x;
+                        const uint32_t u_ = up[G & 1][x];
+                        const uint32_t tcd = u_ & 7u;
+                        const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);   // selector bytes 1..3 = 0 read the zero byte
+                        const int32_t m = (int32_t)((sb << SH) + diag);
+                        const int32_t u = (int32_t)u_ + fc.cU;
+                        const int32_t l = (int32_t)left + fc.cL;
+                        if constexpr (!AFF) {
+                            const uint32_t best = (uint32_t)min(m, min(u, l));
+                            const uint32_t cw = (u_ & TAGS) | (best & ~TAGS);
+                            wr[k * 64] = cw;
+                            // arrow = bits 3..4 of best -> record bits 2k..2k+1
+                            const int sh = (k & 15) * 2 - 3;
+                            const uint32_t ab = sh >= 0 ? (best & 0x18u) << (sh >= 0 ? sh : 0) : (best & 0x18u) >> (sh < 0 ? -sh : 0);
+                            ar[k >> 4] |= ab;
+                            left = cw;
+                        } else {
+                            // gap states: open from the match state (preferred on ties) or extend
+                            const int32_t io = (int32_t)(u_ & ~TAGS) + fc.cIO, ie = (int32_t)ui[G & 1][x] + fc.cIE;
+                            const uint32_t ig = (uint32_t)min(io, ie);                 // bit 2: 1 = extend
+                            const int32_t dop = (int32_t)left + fc.cDO, de = (int32_t)leftD + fc.cDE;
+                            const uint32_t dg = (uint32_t)min(dop, de);                // bit 1: 1 = extend
+                            const int32_t dc = (int32_t)dg + (3 << 3), ic = (int32_t)ig + (4 << 3);
+                            const uint32_t best = (uint32_t)min(min(m, min(u, l)), min(dc, ic));
+                            const uint32_t lc = best & ~TAGS;
+                            wr[k * 64] = lc | tcd;
+                            wr[IOFF + k * 64] = ig & ~TAGS;
+                            // record byte: M arrow (bits 3..5) | I bit (bit 2) | D bit (bit 1)
+                            const uint32_t rbyte = (best & 0x38u) | (ig & 4u) | (dg & 2u);
+                            ar[k >> 2] |= rbyte << ((k & 3) * 8);
+                            left = lc; leftD = dg & ~TAGS;
+                        }
+                        diag = u_;
                     }
                 }
-                const uint32_t ups[4] = {u0, u1, u2, u3};
-                const uint32_t upi[4] = {v0, v1, v2, v3};
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    const int k = K4 + kk;
-                    const uint32_t up = ups[kk];
-                    const uint32_t tcd = up & 7u;
-                    const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);   // selector bytes 1..3 = 0 read the zero byte
-                    const int32_t m = (int32_t)((sb << SH) + diag);
-                    const int32_t u = (int32_t)up + fc.cU;
-                    const int32_t l = (int32_t)left + fc.cL;
-                    if constexpr (!AFF) {
-                        const uint32_t best = (uint32_t)min(m, min(u, l));
-                        const uint32_t cw = (up & TAGS) | (best & ~TAGS);
-                        wr[k * 64] = cw;
-                        // arrow = bits 3..4 of best -> record bits 2k..2k+1
-                        const int sh = (k & 15) * 2 - 3;
-                        const uint32_t ab = sh >= 0 ? (best & 0x18u) << (sh >= 0 ? sh : 0) : (best & 0x18u) >> (sh < 0 ? -sh : 0);
-                        ar[k >> 4] |= ab;
-                        left = cw;
-                    } else {
-                        // gap states: open from the match state (preferred on ties) or extend
-                        const int32_t io = (int32_t)(up & ~TAGS) + fc.cIO, ie = (int32_t)upi[kk] + fc.cIE;
-                        const uint32_t ig = (uint32_t)min(io, ie);                 // bit 2: 1 = extend
-                        const int32_t dop = (int32_t)left + fc.cDO, de = (int32_t)leftD + fc.cDE;
-                        const uint32_t dg = (uint32_t)min(dop, de);                // bit 1: 1 = extend
-                        const int32_t dc = (int32_t)dg + (3 << 3), ic = (int32_t)ig + (4 << 3);
-                        const uint32_t best = (uint32_t)min(min(m, min(u, l)), min(dc, ic));
-                        const uint32_t lc = best & ~TAGS;
-                        wr[k * 64] = lc | tcd;
-                        wr[IOFF + k * 64] = ig & ~TAGS;
-                        // record byte: M arrow (bits 3..5) | I bit (bit 2) | D bit (bit 1)
-                        const uint32_t rb = (best & 0x38u) | (ig & 4u) | (dg & 2u);
-                        ar[k >> 2] |= rb << ((k & 3) * 8);
-                        left = lc; leftD = dg & ~TAGS;
-                    }
-                    diag = up;
-                }
-                u0 = n0; u1 = n1; u2 = n2; u3 = n3;
-                if constexpr (AFF) { v0 = m0; v1 = m1; v2 = m2; v3 = m3; }
             }
-        }
-        if (cells_ok) {
             // record: the arrow dwords of this step (stored whole; the tail past the row end is
             // overwritten by what follows), then the row's meta dword once the row is done
-            const uint32_t ncell = min(W - k0, (uint32_t)CAP);
-#pragma unroll
-            for (int x = 0; x < (AFF ? 8 : 2); x++) rec[x] = ar[x];
-            rec += AFF ? (ncell + 3u) >> 2 : (ncell + 15u) >> 4;
+            if constexpr (AFF) {
+                *(u32x4u *)(recb + rob) = u32x4u{ar[0], ar[1], ar[2], ar[3]};
+                *(u32x4u *)(recb + rob + 16) = u32x4u{ar[NAR - 4], ar[NAR - 3], ar[NAR - 2], ar[NAR - 1]};
+                rob += ((min(rem, (uint32_t)CAP) + 3u) >> 2) * 4u;
+            } else {
+                *(u32x2u *)(recb + rob) = u32x2u{ar[0], ar[1]};
+                rob += rem > 16u ? 8u : 4u;
+            }
             k0 += CAP;
             if (k0 >= W) {
-                rec[0] = meta;
-                rec++;
+                *(uint32_t *)(recb + rob) = meta;
+                rob += 4u;
                 if (rows_left == 0u) {
-                    final_word = lds[(T - (lo + dsh)) * 64 + lane];
+                    final_word = lds[fslot * 64 + lane];
                     finished = true;
                 }
             }
@@ -684,135 +706,133 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
 // record array backwards.  Every lane keeps the TB_RW record dwords that end at its position and
 // TB_TW dwords of target codes in an LDS window ([dword][lane]).  A dependent global load per row
 // would cost a full memory round trip per row; instead ALL lanes of the wave refill their windows
-// together whenever any lane is about to leave its window, one round trip per ~20 rows.
+// together whenever any lane is about to leave one, one round trip per ~20 rows.
+// Linear records hold 2 bits per cell, affine records one byte per cell (M arrow in bits 3..5,
+// insertion-gap bit 2, deletion-gap bit 1).
 constexpr int TB_RW = 64, TB_TW = 16;
-typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+#ifndef GBA_TB_LANES
+#define GBA_TB_LANES 64
+#endif
+constexpr int TB_LANES = GBA_TB_LANES;      // pairs per wave: the walk is a dependent chain, more waves hide more of it
 
-__global__ __launch_bounds__(64) void k_traceback(Dev d, TbConst tc_, gba_pair_result *res)
+template <bool AFF>
+__global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_pair_result *res)
 {
     __shared__ int32_t sub[25];
-    __shared__ uint32_t rwin[TB_RW * 64];
-    __shared__ uint32_t twin[TB_TW * 64];
+    __shared__ uint32_t rwin[TB_RW * TB_LANES];
+    __shared__ uint32_t twin[TB_TW * TB_LANES];
     if (threadIdx.x < 25) sub[threadIdx.x] = tc_.sub[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x;
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t idx = blockIdx.x * TB_LANES + threadIdx.x;
     const uint32_t n_ok = d.plan->n_ok;
-    if (blockIdx.x * blockDim.x >= n_ok) return;
+    if (blockIdx.x * TB_LANES >= n_ok) return;
     const uint32_t p = d.order[idx < n_ok ? idx : n_ok - 1];
     const bool live = idx < n_ok && d.status[p] == GBA_PAIR_OK;   // else: fill found the end cell unreachable
     const uint32_t Q = d.Q[p], T = d.T[p];
     const uint32_t *rec = d.rec + d.rec_off[p];
     const uint32_t *tc4 = (const uint32_t *)(d.tcodes + tc_offset(d, p));   // 4 column codes per dword
-    gba_block *out = d.blk_scratch + d.row_off[p];
-    const uint32_t cap = Q + 1;
+    const uint8_t *twin8 = (const uint8_t *)twin;
+    constexpr uint32_t CSHIFT = AFF ? 2u : 4u, CMASK = AFF ? 3u : 15u, BITS = AFF ? 8u : 2u;
+    uint32_t *outp = (uint32_t *)(d.blk_scratch + d.row_off[p] + Q + 1);     // end of the pair's block scratch
     uint32_t i = Q, j = T, lo = d.lo_last[p], nb = 0, run = 0;
-    uint32_t nM = 0, nX = 0, nI = 0, nD = 0;
+    uint32_t nM = 0, ndiag = 0, nopen = 0;
     int32_t score = 0;
     uint32_t prev_op = 0;
-    uint64_t steps = 0;
+    int32_t pend = 0;                             // substitution cost of the last diagonal move, added one step later
     // affine paths spend an extra step on every gap-state change
-    const uint64_t limit = ((uint64_t)Q + T + 2) * (tc_.mode == GBA_MODE_AFFINE ? 3 : 1);
-    int st = GBA_PAIR_OK;
-    // Linear records hold 2 bits per cell, affine records one byte per cell (M arrow in bits
-    // 3..5, insertion-gap bit 2, deletion-gap bit 1).
-    const bool aff = tc_.mode == GBA_MODE_AFFINE;
-    const uint32_t cshift = aff ? 2u : 4u, cmask = aff ? 3u : 15u, bits = aff ? 8u : 2u;
+    uint32_t budget = (Q + T + 2u) * (AFF ? 3u : 1u);
+    bool ok = true;
     int32_t ptr = (int32_t)d.recdw[p] - 1;        // meta dword of the current row
-    int32_t rb = 0x7fffffff, tb = 0x7fffffff;     // first record dword / code dword held in the windows
-    auto rd_rec = [&](int32_t x) -> uint32_t { return x >= rb ? rwin[(x - rb) * 64 + lane] : rec[x]; };
-    auto rd_tc = [&](int32_t x) -> uint32_t { return x >= tb ? twin[(x - tb) * 64 + lane] : tc4[x]; };
+    int32_t rb = 0x40000000, tb = 0x40000000;     // first record dword / code dword held in the windows
     uint32_t gw = live ? rec[ptr] : 0u;
-    uint32_t tword = live ? tc4[j >> 2] : 0u;
+    uint32_t W = gw & ROW_W_MASK, n = (W + CMASK) >> CSHIFT;   // width, arrow dwords of the current row
     uint32_t state = 0;                           // affine: 0 match state, 1 insertion gap, 2 deletion gap
     for (;;) {
-        const bool active = live && st == GBA_PAIR_OK && (i > 0 || j > 0);
+        const bool active = live && ok && (i | j) != 0u;
         if (!__any(active)) break;
-        const uint32_t W = gw & ROW_W_MASK;
-        const uint32_t n = (W + cmask) >> cshift; // arrow dwords of this row
         {
-            const int32_t look = (int32_t)min(n + 1u, (uint32_t)TB_RW - 1u);
-            if (__any(active && ptr - look < rb)) {
+            const int32_t look = AFF ? (int32_t)min(n + 1u, (uint32_t)TB_RW - 1u) : (int32_t)n + 1;
+            if (__any(active && (ptr - look < rb || (int32_t)(j >> 2) - 1 < tb))) {
                 if (active) {
                     rb = ptr - (TB_RW - 1);
                     const uint32_t *src = rec + rb;
 #pragma unroll
                     for (int c = 0; c < TB_RW / 4; c++) {
                         const u32x4u v = *(const u32x4u *)(src + 4 * c);
-                        uint32_t *w = rwin + (4 * c) * 64 + lane;
-                        w[0] = v.x; w[64] = v.y; w[128] = v.z; w[192] = v.w;
+                        uint32_t *w = rwin + (4 * c) * TB_LANES + lane;
+                        w[0] = v.x; w[TB_LANES] = v.y; w[2 * TB_LANES] = v.z; w[3 * TB_LANES] = v.w;
                     }
-                }
-            }
-            if (__any(active && (int32_t)(j >> 2) - 1 < tb)) {
-                if (active) {
                     tb = (int32_t)(j >> 2) - (TB_TW - 1);
-                    const uint32_t *src = tc4 + tb;
+                    const uint32_t *ts = tc4 + tb;
 #pragma unroll
                     for (int c = 0; c < TB_TW / 4; c++) {
-                        const u32x4u v = *(const u32x4u *)(src + 4 * c);
-                        uint32_t *w = twin + (4 * c) * 64 + lane;
-                        w[0] = v.x; w[64] = v.y; w[128] = v.z; w[192] = v.w;
+                        const u32x4u v = *(const u32x4u *)(ts + 4 * c);
+                        uint32_t *w = twin + (4 * c) * TB_LANES + lane;
+                        w[0] = v.x; w[TB_LANES] = v.y; w[2 * TB_LANES] = v.z; w[3 * TB_LANES] = v.w;
                     }
                 }
             }
         }
-        if (!active) continue;
-        const uint32_t k = j - lo;
-        if (++steps > limit || k >= W) { st = GBA_PAIR_UNREACHABLE; continue; }
-        const uint32_t back = n - (k >> cshift);  // the wanted dword sits `back` dwords before the meta
-        const uint32_t aw = rd_rec(ptr - (int32_t)back);
-        const uint32_t cell = aw >> ((k & cmask) * bits);
-        // move: 0 diagonal, 1 up (insertion), 2 left (deletion), 3 none (state change only), 4 error
-        uint32_t mv;
-        if (!aff) {
-            const uint32_t a = cell & 3u;
-            mv = a == 0u ? 0u : a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : 4u;
-        } else if (state == 0u) {
-            const uint32_t a = (cell >> 3) & 7u;
-            mv = a == 0u ? 0u : a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : 4u;
-            if (a == 3u) { state = 2u; mv = 3u; }
-            if (a == 4u) { state = 1u; mv = 3u; }
-        } else if (state == 1u) {
-            mv = 1u; if ((cell & 4u) == 0u) state = 0u;       // gap opened here: back to the match state
-        } else {
-            mv = 2u; if ((cell & 2u) == 0u) state = 0u;
-        }
-        if (mv == 3u) continue;
-        bool newrow = false;
-        if (mv == 0u) {
-            if (i == 0 || j == 0) { st = GBA_PAIR_UNREACHABLE; continue; }
-            const uint32_t qb = (gw >> 10) & 7u, tbase = ((tword >> ((j & 3u) * 8u)) & 7u) - 1u;
-            if (qb == tbase) nM++; else nX++;
-            score += sub[qb * 5 + tbase];
-            run++; i--; j--; prev_op = 0; newrow = true;
-            if ((j & 3u) == 3u) tword = rd_tc((int32_t)(j >> 2));
-        } else {
-            if (run) { nb++; out[cap - nb] = gba_block{i, j, run}; run = 0; }
-            if (mv == 1u) {
-                if (i == 0) { st = GBA_PAIR_UNREACHABLE; continue; }
-                nI++; i--; newrow = true;
-            } else if (mv == 2u) {
-                if (j == 0) { st = GBA_PAIR_UNREACHABLE; continue; }
-                nD++; j--;
-                if ((j & 3u) == 3u) tword = rd_tc((int32_t)(j >> 2));
-            } else { st = GBA_PAIR_UNREACHABLE; continue; }
-            if (tc_.affine) { if (prev_op != mv) score += tc_.aopen; score += tc_.aext; }
-            else score += mv == 1u ? tc_.ins : tc_.del;
-            prev_op = mv;
-        }
-        if (newrow) {
-            lo -= (gw >> 13) & 1023u;
-            ptr -= (int32_t)n + 1;
-            gw = rd_rec(ptr);
+        if (active) {
+            // The arrow dword, the target code of column j and the meta dword of the row above are
+            // fetched together (one LDS round trip); the last two are only used by some moves.
+            const uint32_t k = j - lo;
+            const bool inband = k < W && budget-- != 0u;
+            const uint32_t kc = inband ? k : 0u;
+            const int32_t at = ptr - (int32_t)(n - (kc >> CSHIFT));     // dword holding cell k
+            const int32_t up = ptr - (int32_t)n - 1;                    // meta dword of row i - 1
+            uint32_t aw, gup;
+            if (AFF && at < rb) aw = rec[at]; else aw = rwin[(at - rb) * TB_LANES + lane];
+            if (AFF && up < rb) gup = rec[up]; else gup = rwin[(up - rb) * TB_LANES + lane];
+            const uint32_t tbase = (uint32_t)twin8[(((j >> 2) - (uint32_t)tb) * TB_LANES + lane) * 4 + (j & 3u)] - 1u;
+            score += pend; pend = 0;
+            const uint32_t cell = aw >> ((kc & CMASK) * BITS);
+            // move: 0 diagonal, 1 up (insertion), 2 left (deletion), 3 none (state change only), 4 error
+            uint32_t mv;
+            if constexpr (!AFF) {
+                const uint32_t a = cell & 3u;
+                mv = a == 0u ? 0u : a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : 4u;
+            } else {
+                const uint32_t a = (cell >> 3) & 7u;
+                const uint32_t m0 = a == 0u ? 0u : a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : a <= 4u ? 3u : 4u;
+                const uint32_t s0 = a == 3u ? 2u : a == 4u ? 1u : 0u;
+                const uint32_t st = state;
+                mv = st == 0u ? m0 : st;                                // in a gap state the move is the gap's own
+                state = st == 0u ? s0 : st == 1u ? ((cell & 4u) ? 1u : 0u) : ((cell & 2u) ? 2u : 0u);
+            }
+            if (!inband || mv == 4u || (i == 0u && (mv == 0u || mv == 1u)) || (j == 0u && (mv == 0u || mv == 2u))) { ok = false; continue; }
+            if (mv == 0u) {
+                const uint32_t qb = (gw >> 10) & 7u;
+                nM += qb == tbase ? 1u : 0u;
+                pend = sub[qb * 5 + tbase];
+                run++; ndiag++; prev_op = 0;
+            } else if (mv != 3u) {
+                if (run) { outp -= 3; outp[0] = i; outp[1] = j; outp[2] = run; nb++; run = 0; }
+                nopen += prev_op != mv ? 1u : 0u;
+                prev_op = mv;
+            }
+            if (mv == 0u || mv == 2u) j--;
+            if (mv == 0u || mv == 1u) {
+                i--;
+                lo -= (gw >> 13) & 1023u;
+                ptr = up;
+                gw = gup;
+                W = gw & ROW_W_MASK; n = (W + CMASK) >> CSHIFT;
+            }
         }
     }
+    score += pend;
     if (!live) return;
     gba_pair_result &R = res[p];
-    if (run) { nb++; out[cap - nb] = gba_block{i, j, run}; }
-    if (st != GBA_PAIR_OK) { d.status[p] = st; nb = 0; }
+    if (run) { outp -= 3; outp[0] = i; outp[1] = j; outp[2] = run; nb++; }
+    if (!ok) { d.status[p] = GBA_PAIR_UNREACHABLE; return; }
+    // every row is consumed by a diagonal or an up move, every column by a diagonal or a left move
+    const uint32_t nI = Q - ndiag, nD = T - ndiag;
+    if (tc_.affine) score += (int32_t)nopen * tc_.aopen + (int32_t)(nI + nD) * tc_.aext;
+    else score += (int32_t)nI * tc_.ins + (int32_t)nD * tc_.del;
     R.n_blk = nb; R.score = score;
-    R.n_match = nM; R.n_mismatch = nX; R.n_ins = nI; R.n_del = nD;
+    R.n_match = nM; R.n_mismatch = ndiag - nM; R.n_ins = nI; R.n_del = nD;
 }
 
 // ---------------------------------------------------------------- results
@@ -1034,7 +1054,11 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (pl.n_ok)
-        hipLaunchKernelGGL(k_traceback, dim3((pl.n_ok + 63) / 64), dim3(64), 0, s, d, c->tbc, res);
+    {
+        const dim3 grid((pl.n_ok + TB_LANES - 1) / TB_LANES), block(TB_LANES);
+        if (sc.mode == GBA_MODE_AFFINE) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, s, d, c->tbc, res);
+        else hipLaunchKernelGGL(k_traceback<false>, grid, block, 0, s, d, c->tbc, res);
+    }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
     hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, s, d, res, out->blocks_capacity, (uint64_t *)c->b_needed.ptr);
     hipLaunchKernelGGL(k_emit, dim3(n), dim3(256), 0, s, d, res, out->blocks);
