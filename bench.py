@@ -22,6 +22,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HBM bytes of one step's k_fill launches, from separate rocprofv3 --pmc passes of this command at the
+# default workload (profiles/r01_step2_hbm_pmc.txt): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction)
+MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 106496): 32207126 * 1024 + 2 * 4223958 * 1024}
 OPS_PER_CELL = 8            # algorithmic int32 ops per DP cell, linear gaps
 BYTES_PER_CELL = 0.25       # algorithmic traceback bytes per cell (2-bit arrows)
 VALU_PEAK_TOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz int32 lane-ops/s (= half the 157.3 TFLOP/s fp32 vector peak)
@@ -69,6 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=106496, help="pairs per GPU per step")
     ap.add_argument("--workload", default="c2_10kb_linear")
+    ap.add_argument("--streams", type=int, default=1, help="contexts per GPU, each on its own stream with pairs/streams pairs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -91,20 +95,43 @@ def main():
     # shard by read index: rank r owns the reads with global index = r (mod world); each rank
     # draws its own shard from a rank-specific seed, per-GPU work is fixed (weak scaling)
     cfg["seed"] = cfg["seed"] + 7919 * rank
-    host = synth.generate(args.pairs, **cfg)
-    scoring = api.make_scoring(band=cfg["band"])
-    dbatch = api.to_device(host, dev)
+    S = max(1, args.streams)
     n = args.pairs
-    cap = int(host["q_len"].astype(np.int64).sum() // 4) + n       # ~1 block per 7.5 bases on this workload
-    out_pairs = torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device=dev)
-    out_blocks = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
-    ctx = api.Context(local, timing=True)
-    ctx.set_scoring(scoring)
+    per = [n // S + (1 if i < n % S else 0) for i in range(S)]
+    hosts, dbatches, outs, ctxs = [], [], [], []
+    scoring = api.make_scoring(band=cfg["band"])
+    for i in range(S):
+        c2 = dict(cfg); c2["seed"] = cfg["seed"] + 104729 * i
+        h = synth.generate(per[i], **c2)
+        hosts.append(h)
+        dbatches.append(api.to_device(h, dev))
+        cap = int(h["q_len"].astype(np.int64).sum() // 4) + per[i]      # ~1 block per 7.5 bases on this workload
+        outs.append((torch.zeros(per[i] * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device=dev),
+                     torch.zeros((cap, 3), dtype=torch.int32, device=dev)))
+        ctx = api.Context(local, timing=True)
+        ctx.set_scoring(scoring)
+        ctxs.append(ctx)
+    host = hosts[0]
 
-    def step():
-        rc, needed = ctx.refine_device(dbatch, out_pairs, out_blocks)
-        if rc != 0:
-            raise RuntimeError("refine_device rc=%d needed=%d cap=%d" % (rc, needed, cap))
+    def run_steps(i, k, acc):
+        for _ in range(k):
+            rc, needed = ctxs[i].refine_device(dbatches[i], outs[i][0], outs[i][1])   # returns when the batch has completed
+            if rc != 0:
+                raise RuntimeError("refine_device rc=%d needed=%d" % (rc, needed))
+            tm = ctxs[i].timing()
+            acc[0] += tm["fill_ms"]; acc[1] += tm["traceback_ms"]
+
+    def run_all(k):
+        accs = [[0.0, 0.0] for _ in range(S)]
+        if S == 1:
+            run_steps(0, k, accs[0])
+        else:
+            ths = [threading.Thread(target=run_steps, args=(i, k, accs[i])) for i in range(S)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        return accs
 
     def barrier():
         torch.cuda.synchronize()
@@ -112,31 +139,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_all(args.warmup)
     barrier()
-    fill_ms = tb_ms = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()                       # gba_submit_device returns when the batch has completed
-        tm = ctx.timing()
-        fill_ms += tm["fill_ms"]
-        tb_ms += tm["traceback_ms"]
+    accs = run_all(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    tm = ctx.timing()
+    fill_ms = sum(a[0] for a in accs) / S
+    tb_ms = sum(a[1] for a in accs) / S
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # sanity: every pair aligned
-    res = out_pairs.cpu().numpy().view(_lib.PAIR_RESULT_DT)
-    n_ok = int((res["status"] == 0).sum())
-    cells_step = int(tm["cells"])
+    n_ok = 0
+    cells_step = 0
+    rec_bytes = 0
+    for i in range(S):
+        res = outs[i][0].cpu().numpy().view(_lib.PAIR_RESULT_DT)
+        n_ok += int((res["status"] == 0).sum())
+        tm = ctxs[i].timing()
+        cells_step += int(tm["cells"])
+        rec_bytes += int(tm["record_bytes"])
     total_cells = cells_step * args.steps * world
     gcups = total_cells / dt / 1e9
     fill_s = fill_ms / 1e3 / args.steps
+    traffic = MEASURED_FILL_TRAFFIC.get((args.workload, n)) if S == 1 else None
     out = {
         "metric": "banded-DP GCUPS (guided banded alignment, refine stage)",
         "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world,
@@ -146,23 +175,23 @@ def main():
         "dtype": "int32", "data": "synthetic",
         "config": {"workload": args.workload, "pairs_per_gpu": n, "read_len": cfg["read_len"],
                    "error": "ins %.2f / del %.2f / sub %.2f" % (cfg["p_ins"], cfg["p_del"], cfg["p_sub"]),
-                   "band": cfg["band"], "gaps": cfg["mode"], "reference_len": cfg["ref_len"],
+                   "streams": S, "band": cfg["band"], "gaps": cfg["mode"], "reference_len": cfg["ref_len"],
                    "cells_per_step_per_gpu": cells_step, "pairs_ok": n_ok,
                    "parallelism": "reads sharded by index, %d rank(s), no collective" % world},
         "aligned_reads_per_sec": round(n * args.steps * world / dt, 1),
         "roofline": {
-            "bound": "valu-int32", "kernel": "k_fill_linear",
+            "bound": "valu-int32", "kernel": "k_fill<false>",
             "achieved": round(cells_step * OPS_PER_CELL / fill_s / 1e12, 3), "peak": VALU_PEAK_TOPS,
             "unit": "Tops/s", "frac": round(cells_step * OPS_PER_CELL / fill_s / 1e12 / VALU_PEAK_TOPS, 4),
             "ops_per_cell": OPS_PER_CELL, "fill_ms": round(fill_s * 1e3, 3),
             "fill_gcups": round(cells_step / fill_s / 1e9, 2),
-            "traffic": None,
+            "traffic": traffic,
         },
         "roofline_hbm": {
-            "bound": "hbm", "kernel": "k_fill_linear",
+            "bound": "hbm", "kernel": "k_fill<false>",
             "achieved": round(cells_step * BYTES_PER_CELL / fill_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(cells_step * BYTES_PER_CELL / fill_s / 1e9 / HBM_PEAK_GBS, 5),
-            "record_bytes_written": int(tm["record_bytes"]), "traffic": None,
+            "record_bytes_written": rec_bytes, "traffic": traffic,
         },
         "traceback_ms": round(tb_ms / args.steps, 3),
     }

@@ -598,17 +598,18 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
             newslot += 8u;
         }
         if (pop_row || pop_ext) { wc++; hs = hs == FIFO_WORDS - 1 ? 0u : hs + 1u; }
-        // peek the following word (not needed before the next step)
+        // peek the following word (not needed before the next step); the matrix row of its query
+        // base is looked up after the cells, when the word has long arrived
         nword = fifo[hs * 64 + lane];
-        nmlo = tab[((nword >> 10) & 7u) * 2]; nmhi = tab[((nword >> 10) & 7u) * 2 + 1];
         // ---- 2. up to CAP cells of the current row, in groups of 8
-        if (!finished && ext_left == 0u && k0 < W) {
+        const bool did = !finished && ext_left == 0u && k0 < W;
+        const uint32_t rem = W - k0;
+        uint32_t ar[NAR];
+#pragma unroll
+        for (int x = 0; x < NAR; x++) ar[x] = 0;
+        if (did) {
             const uint32_t *rd = lds + (dsh + k0) * 64 + lane;
             uint32_t *wr = lds + k0 * 64 + lane;
-            const uint32_t rem = W - k0;
-            uint32_t ar[NAR];
-#pragma unroll
-            for (int x = 0; x < NAR; x++) ar[x] = 0;
             uint32_t up[2][8], ui[2][8];
 #pragma unroll
             for (int x = 0; x < 8; x++) { up[0][x] = rd[x * 64]; if constexpr (AFF) ui[0][x] = rd[IOFF + x * 64]; }
@@ -660,6 +661,19 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                     }
                 }
             }
+        }
+        nmlo = tab[((nword >> 10) & 7u) * 2]; nmhi = tab[((nword >> 10) & 7u) * 2 + 1];
+        // the refill is installed before this step's record stores are issued, so that its wait
+        // only covers the load (requested a whole step ago) and older stores
+        if ((it & 3u) == 0u) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf) : : "memory");
+            if (refill) {
+                uint32_t *f = fifo + is * 64 + lane;
+                f[0] = pf.x; f[64] = pf.y; f[128] = pf.z; f[192] = pf.w;
+                wi += 4; is = is == FIFO_WORDS - 4 ? 0u : is + 4u;
+            }
+        }
+        if (did) {
             // record: the arrow dwords of this step (stored whole; the tail past the row end is
             // overwritten by what follows), then the row's meta dword once the row is done
             if constexpr (AFF) {
@@ -678,14 +692,6 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                     final_word = lds[fslot * 64 + lane];
                     finished = true;
                 }
-            }
-        }
-        if ((it & 3u) == 0u) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf) : : "memory");
-            if (refill) {
-                uint32_t *f = fifo + is * 64 + lane;
-                f[0] = pf.x; f[64] = pf.y; f[128] = pf.z; f[192] = pf.w;
-                wi += 4; is = is == FIFO_WORDS - 4 ? 0u : is + 4u;
             }
         }
     }
