@@ -575,16 +575,7 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
             ext_left = nnew > 3u ? (nnew + 4u) >> 3 : 0u;
             newslot = Wp + 3u;
             k0 = 0;
-            // the diagonal predecessor of the row's first cell (INFW when it lies outside the previous row)
-            const uint32_t dv = lds[(max(dsh, 1u) - 1u) * 64 + lane];
-            diag = dsh - 1u < Wp ? dv : INFW;
             left = INFW; leftD = INFW;
-            if (first) {
-                // row 0: linear starts from "one deletion before column 0" so that cell j costs j
-                // deletions; affine makes the diagonal candidate of cell (0,0) cost exactly 0
-                if constexpr (AFF) diag = (uint32_t)fc.diag0; else left = (uint32_t)(-fc.del * 32);
-            }
-            first = false;
             meta = word & ROW_META_MASK;
         }
         if (pop_ext) {
@@ -607,12 +598,28 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
         uint32_t ar[NAR];
 #pragma unroll
         for (int x = 0; x < NAR; x++) ar[x] = 0;
-        if (did) {
-            const uint32_t *rd = lds + (dsh + k0) * 64 + lane;
-            uint32_t *wr = lds + k0 * 64 + lane;
-            uint32_t up[2][8], ui[2][8];
+        // One LDS round trip for everything the step's first cells need: the diagonal predecessor of
+        // a new row's first cell and the vertical predecessors of the first 8 cells (lanes without
+        // cells this step read slots 0..7, which always exist).
+        const uint32_t *rd = lds + (did ? dsh + k0 : 0u) * 64 + lane;
+        uint32_t up[2][8], ui[2][8];
+        {
+            const uint32_t dv = lds[(max(dsh, 1u) - 1u) * 64 + lane];
 #pragma unroll
             for (int x = 0; x < 8; x++) { up[0][x] = rd[x * 64]; if constexpr (AFF) ui[0][x] = rd[IOFF + x * 64]; }
+            if (pop_row) {
+                // INFW when the diagonal predecessor lies outside the previous row
+                diag = dsh - 1u < Wp ? dv : INFW;
+                if (first) {
+                    // row 0: linear starts from "one deletion before column 0" so that cell j costs j
+                    // deletions; affine makes the diagonal candidate of cell (0,0) cost exactly 0
+                    if constexpr (AFF) diag = (uint32_t)fc.diag0; else left = (uint32_t)(-fc.del * 32);
+                }
+                first = false;
+            }
+        }
+        if (did) {
+            uint32_t *wr = lds + k0 * 64 + lane;
 #pragma unroll
             for (int G = 0; G < CAP / 8; G++) {
                 if (rem > (uint32_t)(8 * G)) {
