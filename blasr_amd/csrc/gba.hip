@@ -46,7 +46,10 @@ constexpr uint32_t MAX_ROWS_AFFINE = 32767;  // affine words carry one more tag 
 constexpr uint32_t MAX_COLS = 1u << 20;
 // Classes of the lane-per-pair fill kernel: a pair's class is the smallest LDS row buffer
 // (32 << class slots) that holds its widest "shift + width".  Each non-empty class is one launch.
-constexpr int NCLS = 5;                      // 32, 64, 128, 256, 512 slots (affine: up to 256, it keeps two rings)
+constexpr int NCLS = 5;                      // lane-per-pair classes of 32, 64, 128, 256 slots, then the wave-per-pair class
+constexpr int CLS_WIDE = NCLS - 1;           // pairs of the linear modes too wide for the lane classes in use: k_fill_wide
+constexpr int LANE_CLS_LINEAR = 3;           // linear gaps: lane classes up to 128 slots, anything wider is cheaper wave-per-pair
+constexpr int LANE_CLS_AFFINE = 4;           // affine gaps: lane classes up to 256 slots (two rings), no wave-per-pair kernel
 constexpr int PAD_SLOTS = 3;                 // spare slots behind a ring
 constexpr int SPAN_MARGIN = 4;               // a pair fits a class if its widest shift + width <= slots - SPAN_MARGIN (k_fill touches up to 7 slots past a row end)
 constexpr int CAP = 32;                      // cells per lane per step of k_fill
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
 // `order` lists the OK pairs grouped by class (stable); rec_off is each pair's record offset in
 // dwords (4 spare dwords precede every pair: the traceback reads 16-byte windows ending at a row;
 // 8 follow it: the fill kernel stores whole steps and lets the next store overwrite the tail).  Pairs whose widest row needs more than the largest class are TOO_WIDE.
-__global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls)
+__global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
 {
     __shared__ uint64_t sm[17];
     __shared__ uint32_t cnt[NCLS + 1], base[NCLS + 1], run[NCLS + 1];
@@ -430,6 +433,7 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls)
         if (d.status[p] == GBA_PAIR_OK) {
             const uint32_t s = d.span[p];
             for (int k = ncls - 1; k >= 0; k--) if (s + SPAN_MARGIN <= cls_slots(k)) c = (uint32_t)k;
+            if (c == NCLS && has_wide) c = CLS_WIDE;
             if (c == NCLS) d.status[p] = GBA_PAIR_TOO_WIDE;
             else atomicAdd(&cnt[c], 1u);
         }
@@ -709,6 +713,123 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     }
 }
 
+// ---------------------------------------------------------------- k_fill_wide
+// Wave-per-pair fill for wide bands (linear gaps): one LANE per COLUMN, 64 columns per chunk, the
+// chunks of a row in sequence.  The previous row sits in an LDS ring of the wave (slot = column -
+// first column of the row, as in k_fill); a cell's vertical predecessor is slot k + shift, its
+// diagonal predecessor the value the lane to the left read.  The dependency along the row
+// (deletions) is a min-plus scan: with S(j) the best score of column j over its diagonal and
+// vertical moves, the left candidate of column k is  min over j < k of S(j) + (k - j) * del,
+// i.e. an exclusive prefix minimum of S(j) - j * del across the lanes plus k * del, with the last
+// column of the previous chunk carried in.  Cell words, tie-break (the arrow code rides in the
+// compared word) and records are exactly those of k_fill.
+//
+// Guide words are staged through an LDS ring of the wave, refilled 64 words at a time.
+constexpr int WIDE_RING = 2048 + 64;          // shift + width <= 2046, lanes run up to 63 columns past the row end
+constexpr int WIDE_SBUF = 512;                // guide words buffered per wave (a row has at most 1 + 128)
+
+__device__ __forceinline__ int32_t wave_scan_min(int32_t v, int32_t identity)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(identity, v, 0x111, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(identity, v, 0x112, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(identity, v, 0x114, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(identity, v, 0x142, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(identity, v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc)
+{
+    __shared__ uint32_t ring[WIDE_RING];
+    __shared__ uint32_t sbuf[WIDE_SBUF];
+    __shared__ uint32_t tab[LDS_TAB];
+    constexpr uint32_t TAGS = 31u;
+    constexpr int32_t BIG = 0x60000000;                 // identity of the prefix minimum (no overflow when offsets are added)
+    const int lane = threadIdx.x;
+    if (lane < 10) tab[lane] = fc.mrow[lane];
+    const uint32_t p = d.order[d.plan->cls_base[CLS_WIDE] + blockIdx.x];
+    const uint32_t Q = d.Q[p];
+    const uint32_t fslot = d.T[p] - d.lo_last[p];       // slot of the end cell (Q, T) in the last row
+    const uint32_t *st = d.stream + d.word_off[p];
+    const uint32_t wcap = d.wcap[p];
+    uint32_t *rec = d.rec + d.rec_off[p];
+    const int32_t D = fc.del * 32;                      // one deletion, in cell-word units
+    const int32_t codeL = fc.cL - D;                    // arrow code of a deletion (<< 3)
+    uint32_t spos = 0, sload = 0;                       // guide words consumed / loaded
+    uint32_t W = 0, Wp = 0, dsh = 0, roff = 0;
+    __syncthreads();
+    for (uint32_t r = 0; r <= Q; r++) {
+        // keep at least 256 guide words buffered (or everything that is left)
+        while (sload - spos < 256u && sload < wcap) {
+            const uint32_t x = sload + lane;
+            const uint32_t v = x < wcap ? st[x] : 0u;
+            sbuf[x & (WIDE_SBUF - 1)] = v;
+            sload += 64;
+        }
+        __syncthreads();
+        const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)sbuf[spos & (WIDE_SBUF - 1)]);
+        Wp = W;
+        W = word & ROW_W_MASK; dsh = (word >> 13) & 1023u;
+        const uint32_t qcode = (word >> 10) & 7u;
+        const uint32_t mlo = tab[qcode * 2], mhi = tab[qcode * 2 + 1];
+        const uint32_t tot = dsh + W;
+        const uint32_t nnew = tot > Wp ? tot - Wp : 0u;
+        // entering columns: INFW words carrying the column's base code
+        for (uint32_t x = lane; x < nnew; x += 64) {
+            uint32_t code;
+            if (x < 3u) code = (word >> (23u + 3u * x)) & 7u;
+            else {
+                const uint32_t e = (x - 3u) >> 3, rr = (x - 3u) & 7u;
+                code = (sbuf[(spos + 1u + e) & (WIDE_SBUF - 1)] >> (3u * rr)) & 7u;
+            }
+            ring[Wp + x] = INFW | code;
+        }
+        spos += 1u + (nnew > 3u ? (nnew + 4u) >> 3 : 0u);
+        __syncthreads();
+        // carries into the first chunk: the diagonal predecessor of column 0 and "the cell left of it"
+        uint32_t cdiag = dsh >= 1u && dsh - 1u < Wp ? ring[dsh - 1u] : INFW;
+        int32_t hc = r == 0 ? -D : (int32_t)INFW;       // row 0: column j costs j deletions
+        const uint32_t nd = (W + 15u) >> 4;
+        for (uint32_t c0 = 0; c0 < W; c0 += 64) {
+            const uint32_t k = c0 + lane;
+            const uint32_t up = ring[k + dsh];
+            const uint32_t diag = (uint32_t)__builtin_amdgcn_update_dpp((int32_t)cdiag, (int32_t)up, 0x138, 0xf, 0xf, false);
+            cdiag = (uint32_t)__builtin_amdgcn_readlane((int32_t)up, 63);
+            const uint32_t tcd = up & 7u;
+            const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);
+            const int32_t m = (int32_t)((sb << 5) + diag);
+            const int32_t u = (int32_t)up + fc.cU;
+            const int32_t xv = min(m, u);                               // best of the two moves from the previous row
+            const int32_t a = (int32_t)((uint32_t)xv & ~TAGS) - lane * D;
+            const int32_t incl = wave_scan_min(a, BIG);
+            const int32_t excl = __builtin_amdgcn_update_dpp(BIG, incl, 0x138, 0xf, 0xf, false);
+            const int32_t lc = min(excl + lane * D, hc + (lane + 1) * D) + codeL;
+            __syncthreads();                                            // every lane has read its slots before any is overwritten
+            const uint32_t best = (uint32_t)min(xv, lc);
+            const uint32_t cw = (up & TAGS) | (best & ~TAGS);
+            ring[k] = cw;
+            hc = __builtin_amdgcn_readlane((int32_t)(best & ~TAGS), 63);
+            // arrows: 2 bits per column, 16 columns per dword
+            int32_t ab = (int32_t)(((best >> 3) & 3u) << (2 * (lane & 15)));
+            ab |= __builtin_amdgcn_update_dpp(0, ab, 0x111, 0xf, 0xf, false);
+            ab |= __builtin_amdgcn_update_dpp(0, ab, 0x112, 0xf, 0xf, false);
+            ab |= __builtin_amdgcn_update_dpp(0, ab, 0x114, 0xf, 0xf, false);
+            ab |= __builtin_amdgcn_update_dpp(0, ab, 0x118, 0xf, 0xf, false);
+            const uint32_t dwi = (c0 >> 4) + ((uint32_t)lane >> 4);
+            if ((lane & 15) == 15 && dwi < nd) rec[roff + dwi] = (uint32_t)ab;
+        }
+        if (lane == 0) rec[roff + nd] = word & ROW_META_MASK;
+        roff += nd + 1u;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        const int32_t v = (int32_t)(ring[fslot] & ~TAGS) - (int32_t)Q * (128 << 5);
+        if (v >= UNREACH) d.status[p] = GBA_PAIR_UNREACHABLE;
+        d.dp_score[p] = v >> 5;
+    }
+}
+
 // ---------------------------------------------------------------- k_traceback
 // One lane per pair: from the end cell (Q, T) follow the arrows to (0, 0); merge diagonal runs
 // into blocks (ArrowPathToAlignment), count matches / mismatches / gaps and rescore the path
@@ -765,7 +886,7 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
         const bool active = live && ok && (i | j) != 0u;
         if (!__any(active)) break;
         {
-            const int32_t look = AFF ? (int32_t)min(n + 1u, (uint32_t)TB_RW - 1u) : (int32_t)n + 1;
+            const int32_t look = (int32_t)min(n + 1u, (uint32_t)TB_RW - 1u);
             if (__any(active && (ptr - look < rb || (int32_t)(j >> 2) - 1 < tb))) {
                 if (active) {
                     rb = ptr - (TB_RW - 1);
@@ -796,8 +917,8 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
             const int32_t at = ptr - (int32_t)(n - (kc >> CSHIFT));     // dword holding cell k
             const int32_t up = ptr - (int32_t)n - 1;                    // meta dword of row i - 1
             uint32_t aw, gup;
-            if (AFF && at < rb) aw = rec[at]; else aw = rwin[(at - rb) * TB_LANES + lane];
-            if (AFF && up < rb) gup = rec[up]; else gup = rwin[(up - rb) * TB_LANES + lane];
+            if (at < rb) aw = rec[at]; else aw = rwin[(at - rb) * TB_LANES + lane];    // rows wider than the window
+            if (up < rb) gup = rec[up]; else gup = rwin[(up - rb) * TB_LANES + lane];
             const uint32_t tbase = (uint32_t)twin8[(((j >> 2) - (uint32_t)tb) * TB_LANES + lane) * 4 + (j & 3u)] - 1u;
             score += pend; pend = 0;
             const uint32_t cell = aw >> ((kc & CMASK) * BITS);
@@ -963,8 +1084,8 @@ int launch_fill(gba_ctx *c, const Dev &d, uint32_t cls, uint32_t count, hipStrea
     const size_t lds = (rings * (slots + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        const size_t mx1 = ((size_t)(cls_slots(NCLS - 1) + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
-        const size_t mx2 = (2 * (size_t)(cls_slots(NCLS - 2) + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
+        const size_t mx1 = ((size_t)(cls_slots(LANE_CLS_LINEAR - 1) + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
+        const size_t mx2 = (2 * (size_t)(cls_slots(LANE_CLS_AFFINE - 1) + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
         const size_t mx = mx1 > mx2 ? mx1 : mx2;
         HIPCHK(c, hipFuncSetAttribute((const void *)k_fill<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_fill<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
@@ -1028,7 +1149,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
 
     hipLaunchKernelGGL(k_pack, dim3(n), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_guide, dim3(n), dim3(64), 0, s, d, sc.mode, sc.band, sc.max_band, sc.kband_k);
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, d, sc.mode == GBA_MODE_AFFINE ? NCLS - 1 : NCLS);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, d, sc.mode == GBA_MODE_AFFINE ? LANE_CLS_AFFINE : LANE_CLS_LINEAR, sc.mode == GBA_MODE_AFFINE ? 0 : 1);
     HIPCHK(c, hipMemcpyAsync(c->h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const Plan pl = *c->h_plan;
@@ -1055,8 +1176,13 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
                 HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0));
                 used[a] = true;
             }
-            int rc = launch_fill(c, d, (uint32_t)k, cnt, st);
-            if (rc) return rc;
+            if (k == CLS_WIDE && sc.mode != GBA_MODE_AFFINE) {
+                hipLaunchKernelGGL(k_fill_wide, dim3(cnt), dim3(64), 0, st, d, c->fc);
+                HIPCHK(c, hipGetLastError());
+            } else {
+                int rc = launch_fill(c, d, (uint32_t)k, cnt, st);
+                if (rc) return rc;
+            }
             launches++;
         }
         for (int a = 0; a < NAUX; a++) {

@@ -77,22 +77,23 @@ def test_wide_band(ctx, api, oracle, synth):
     batch = synth.generate(24, read_len=3000, p_ins=0.11, p_del=0.06, p_sub=0.03, seed=5000)
     _run(ctx, api, oracle, batch, band=40)
     _run(ctx, api, oracle, batch, band=100)
-    _run(ctx, api, oracle, batch, band=200)          # rows of ~400 cells: the 512-slot class
+    _run(ctx, api, oracle, batch, band=200)          # rows of ~400 cells: the wave-per-pair kernel
 
 
-def test_c5_band250_and_too_wide(ctx, api, oracle, synth):
-    from blasr_amd import _lib
+def test_c5_band250(ctx, api, oracle, synth):
+    # rows of a band-250 guide have up to 501 cells plus the shift: all of them go to the
+    # wave-per-pair kernel, none is refused
     batch = synth.generate(8, read_len=6000, p_ins=0.11, p_del=0.06, p_sub=0.03, seed=5001)
-    ctx.set_scoring(api.make_scoring(band=250))
-    pairs, blocks, rc = ctx.refine_host(batch)
-    ores, oblk = oracle.align_batch(batch, oracle.make_params(band=250))
-    for p in range(8):
-        # rows of a band-250 guide need up to 501 slots plus the shift; pairs beyond 512 are refused
-        if int(pairs[p]["status"]) == _lib.PAIR_TOO_WIDE:
-            continue
-        for f in util.FIELDS:
-            assert int(ores[p][f]) == int(pairs[p][f]), (f, p)
-    assert (pairs["status"] == 0).sum() >= 1
+    pairs, _ = _run(ctx, api, oracle, batch, band=250)
+    assert int((pairs["status"] == 0).sum()) == 8
+    _run(ctx, api, oracle, batch, band=250, tie_break=1, ins=3, dele=6)
+
+
+def test_wide_mixed_classes(ctx, api, oracle, synth):
+    # one batch whose pairs spread over the lane-per-pair classes and the wave-per-pair class
+    batch = synth.generate(160, read_len=2500, len_jitter=1500, p_ins=0.12, p_del=0.08, p_sub=0.03, seed=5002)
+    _run(ctx, api, oracle, batch, band=30)
+    _run(ctx, api, oracle, batch, band=55)
 
 
 @pytest.mark.parametrize("kw", [dict(tie_break=1), dict(n_score=3), dict(band=0), dict(band=3),
