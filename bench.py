@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=106496, help="pairs per GPU per step")
     ap.add_argument("--workload", default="c2_10kb_linear")
+    ap.add_argument("--band", type=int, default=None, help="override the preset's band")
     ap.add_argument("--streams", type=int, default=1, help="contexts per GPU, each on its own stream with pairs/streams pairs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -99,7 +100,10 @@ def main():
     n = args.pairs
     per = [n // S + (1 if i < n % S else 0) for i in range(S)]
     hosts, dbatches, outs, ctxs = [], [], [], []
-    scoring = api.make_scoring(band=cfg["band"])
+    if args.band is not None:
+        cfg["band"] = args.band
+    affine = cfg["mode"] == "affine"
+    scoring = api.make_scoring(band=cfg["band"], mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR)
     for i in range(S):
         c2 = dict(cfg); c2["seed"] = cfg["seed"] + 104729 * i
         h = synth.generate(per[i], **c2)
@@ -165,6 +169,7 @@ def main():
     total_cells = cells_step * args.steps * world
     gcups = total_cells / dt / 1e9
     fill_s = fill_ms / 1e3 / args.steps
+    ops_cell, bytes_cell = (18, 0.75) if affine else (OPS_PER_CELL, BYTES_PER_CELL)   # algorithmic work per cell
     traffic = MEASURED_FILL_TRAFFIC.get((args.workload, n)) if S == 1 else None
     out = {
         "metric": "banded-DP GCUPS (guided banded alignment, refine stage)",
@@ -180,17 +185,17 @@ def main():
                    "parallelism": "reads sharded by index, %d rank(s), no collective" % world},
         "aligned_reads_per_sec": round(n * args.steps * world / dt, 1),
         "roofline": {
-            "bound": "valu-int32", "kernel": "k_fill<false>",
-            "achieved": round(cells_step * OPS_PER_CELL / fill_s / 1e12, 3), "peak": VALU_PEAK_TOPS,
-            "unit": "Tops/s", "frac": round(cells_step * OPS_PER_CELL / fill_s / 1e12 / VALU_PEAK_TOPS, 4),
-            "ops_per_cell": OPS_PER_CELL, "fill_ms": round(fill_s * 1e3, 3),
+            "bound": "valu-int32", "kernel": "k_fill<%s>" % ("true" if affine else "false"),
+            "achieved": round(cells_step * ops_cell / fill_s / 1e12, 3), "peak": VALU_PEAK_TOPS,
+            "unit": "Tops/s", "frac": round(cells_step * ops_cell / fill_s / 1e12 / VALU_PEAK_TOPS, 4),
+            "ops_per_cell": ops_cell, "fill_ms": round(fill_s * 1e3, 3),
             "fill_gcups": round(cells_step / fill_s / 1e9, 2),
             "traffic": traffic,
         },
         "roofline_hbm": {
             "bound": "hbm", "kernel": "k_fill<false>",
-            "achieved": round(cells_step * BYTES_PER_CELL / fill_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(cells_step * BYTES_PER_CELL / fill_s / 1e9 / HBM_PEAK_GBS, 5),
+            "achieved": round(cells_step * bytes_cell / fill_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(cells_step * bytes_cell / fill_s / 1e9 / HBM_PEAK_GBS, 5),
             "record_bytes_written": rec_bytes, "traffic": traffic,
         },
         "traceback_ms": round(tb_ms / args.steps, 3),

@@ -52,8 +52,8 @@ constexpr int LANE_CLS_LINEAR = 3;           // linear gaps: lane classes up to 
 constexpr int LANE_CLS_AFFINE = 4;           // affine gaps: lane classes up to 256 slots (two rings), no wave-per-pair kernel
 constexpr int PAD_SLOTS = 3;                 // spare slots behind a ring
 constexpr int SPAN_MARGIN = 4;               // a pair fits a class if its widest shift + width <= slots - SPAN_MARGIN (k_fill touches up to 7 slots past a row end)
-constexpr int CAP = 32;                      // cells per lane per step of k_fill
-constexpr size_t ARENA_SLACK = 256;          // bytes in front of the record / target-code arenas: k_traceback's windows start before a pair's data
+constexpr int CAP_LINEAR = 32, CAP_AFFINE = 40;   // cells per lane per step of k_fill (band 10 rows are 21+ cells, band 16 rows 33+)
+constexpr size_t ARENA_SLACK = 16384 + 256;          // bytes in front of the record / target-code arenas: k_traceback's windows start before a pair's data
 __host__ __device__ constexpr uint32_t cls_slots(int c) { return 32u << c; }
 
 // Guide stream words (one stream per pair, built by k_guide, consumed by k_fill):
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
 // ---------------------------------------------------------------- k_plan
 // `order` lists the OK pairs grouped by class (stable); rec_off is each pair's record offset in
 // dwords (4 spare dwords precede every pair: the traceback reads 16-byte windows ending at a row;
-// 8 follow it: the fill kernel stores whole steps and lets the next store overwrite the tail).  Pairs whose widest row needs more than the largest class are TOO_WIDE.
+// 12 follow it: the fill kernel stores whole steps and lets the next store overwrite the tail).  Pairs whose widest row needs more than the largest class are TOO_WIDE.
 __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
 {
     __shared__ uint64_t sm[17];
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
             if (threadIdx.x == 0) run[k] += (uint32_t)tot;
             __syncthreads();
         }
-        const uint64_t rd = c < NCLS ? (uint64_t)d.recdw[p] + 12u : 0;
+        const uint64_t rd = c < NCLS ? (uint64_t)d.recdw[p] + 16u : 0;
         uint64_t e = block_excl_scan(rd, sm, &tot);
         if (p < d.n) d.rec_off[p] = carry + e + 4u;
         carry += tot;
@@ -506,7 +506,8 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     extern __shared__ uint32_t smem[];
     constexpr int SH = AFF ? 6 : 5;                     // score shift of a cell word
     constexpr uint32_t TAGS = (1u << SH) - 1u;
-    constexpr int NAR = AFF ? 8 : 2;                    // record dwords of one step
+    constexpr int CAP = AFF ? CAP_AFFINE : CAP_LINEAR;
+    constexpr int NAR = AFF ? CAP / 4 : CAP / 16;       // record dwords of one step
     const int lane = threadIdx.x;
     const uint32_t SL = slots + PAD_SLOTS;              // slots of one ring
     uint32_t *tab = smem, *fifo = smem + LDS_TAB, *lds = smem + LDS_TAB + LDS_FIFO;
@@ -688,8 +689,9 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
             // record: the arrow dwords of this step (stored whole; the tail past the row end is
             // overwritten by what follows), then the row's meta dword once the row is done
             if constexpr (AFF) {
-                *(u32x4u *)(recb + rob) = u32x4u{ar[0], ar[1], ar[2], ar[3]};
-                *(u32x4u *)(recb + rob + 16) = u32x4u{ar[NAR - 4], ar[NAR - 3], ar[NAR - 2], ar[NAR - 1]};
+#pragma unroll
+                for (int x = 0; x + 4 <= NAR; x += 4) *(u32x4u *)(recb + rob + 4 * x) = u32x4u{ar[x], ar[x + 1], ar[x + 2], ar[x + 3]};
+                if constexpr (NAR % 4 == 2) *(u32x2u *)(recb + rob + 4 * (NAR - 2)) = u32x2u{ar[NAR - 2], ar[NAR - 1]};
                 rob += ((min(rem, (uint32_t)CAP) + 3u) >> 2) * 4u;
             } else {
                 *(u32x2u *)(recb + rob) = u32x2u{ar[0], ar[1]};
@@ -850,7 +852,7 @@ constexpr int TB_RW = 64, TB_TW = 16;
 constexpr int TB_LANES = GBA_TB_LANES;      // pairs per wave: the walk is a dependent chain, more waves hide more of it
 
 template <bool AFF>
-__global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_pair_result *res)
+__global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_pair_result *res, uint32_t n_lane)
 {
     __shared__ int32_t sub[25];
     __shared__ uint32_t rwin[TB_RW * TB_LANES];
@@ -859,7 +861,7 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
     __syncthreads();
     const int lane = threadIdx.x;
     const uint32_t idx = blockIdx.x * TB_LANES + threadIdx.x;
-    const uint32_t n_ok = d.plan->n_ok;
+    const uint32_t n_ok = n_lane;                 // pairs of the lane-per-pair classes come first in `order`
     if (blockIdx.x * TB_LANES >= n_ok) return;
     const uint32_t p = d.order[idx < n_ok ? idx : n_ok - 1];
     const bool live = idx < n_ok && d.status[p] == GBA_PAIR_OK;   // else: fill found the end cell unreachable
@@ -962,6 +964,110 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
     if (run) { outp -= 3; outp[0] = i; outp[1] = j; outp[2] = run; nb++; }
     if (!ok) { d.status[p] = GBA_PAIR_UNREACHABLE; return; }
     // every row is consumed by a diagonal or an up move, every column by a diagonal or a left move
+    const uint32_t nI = Q - ndiag, nD = T - ndiag;
+    if (tc_.affine) score += (int32_t)nopen * tc_.aopen + (int32_t)(nI + nD) * tc_.aext;
+    else score += (int32_t)nI * tc_.ins + (int32_t)nD * tc_.del;
+    R.n_blk = nb; R.score = score;
+    R.n_match = nM; R.n_mismatch = ndiag - nM; R.n_ins = nI; R.n_del = nD;
+}
+
+// ---------------------------------------------------------------- k_traceback_wide
+// Traceback of the wave-per-pair class: the rows of such pairs have records of up to 65 dwords, so
+// a lane-private window would hold two or three rows.  Here a WAVE serves one pair: all lanes
+// load the next WT_WIN record dwords (and WT_TC target codes) into LDS with coalesced 16-byte
+// loads, then lane 0 walks the rows that window covers.  Same records, moves and statistics as
+// k_traceback<false>.
+constexpr int WT_WIN = 4096;      // record dwords per refill
+constexpr int WT_TC = 2048;       // target codes (bytes) per refill
+
+__global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_pair_result *res)
+{
+    __shared__ int32_t sub[25];
+    __shared__ __attribute__((aligned(16))) uint32_t win[WT_WIN];
+    __shared__ uint32_t tcw[WT_TC / 4];
+    if (threadIdx.x < 25) sub[threadIdx.x] = tc_.sub[threadIdx.x];
+    const int lane = threadIdx.x;
+    const uint32_t p = d.order[d.plan->cls_base[CLS_WIDE] + blockIdx.x];
+    if (d.status[p] != GBA_PAIR_OK) return;             // fill found the end cell unreachable
+    const uint32_t Q = d.Q[p], T = d.T[p];
+    const uint32_t *rec = d.rec + d.rec_off[p];
+    const uint8_t *tc = d.tcodes + tc_offset(d, p);
+    const uint8_t *tcw8 = (const uint8_t *)tcw;
+    uint32_t *outp = (uint32_t *)(d.blk_scratch + d.row_off[p] + Q + 1);     // end of the pair's block scratch
+    // The walk is wave-uniform: every lane follows the same path, LDS values are made scalar right
+    // after they are read, so the whole state machine runs on the scalar unit; only lane 0 stores.
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)v); };
+    uint32_t i = Q, j = T, lo = uni(d.lo_last[p]), nb = 0, run = 0;
+    uint32_t nM = 0, ndiag = 0, nopen = 0, prev_op = 0;
+    int32_t score = 0;
+    uint32_t budget = Q + T + 2u;
+    bool ok = true, done = false;
+    int32_t pend_v = 0;
+    int32_t ptr = (int32_t)uni(d.recdw[p]) - 1;         // meta dword of the current row
+    while (!done) {
+        // refill: records [rb, rb + WT_WIN) ending at ptr, target codes [jb, jb + WT_TC) ending at column j
+        const int32_t rb = ptr - (WT_WIN - 1);
+        const int32_t jb = ((int32_t)j | 3) - (WT_TC - 1);               // multiple of 4
+        __syncthreads();
+        {
+            u32x4u v[WT_WIN / 256];
+            uint32_t t[WT_TC / 256];
+#pragma unroll
+            for (int x = 0; x < WT_WIN / 256; x++) v[x] = *(const u32x4u *)(rec + rb + x * 256 + lane * 4);   // may start before the pair's records (arena slack)
+#pragma unroll
+            for (int x = 0; x < WT_TC / 256; x++) t[x] = *(const uint32_t *)(tc + jb + x * 256 + lane * 4);
+#pragma unroll
+            for (int x = 0; x < WT_WIN / 256; x++) *(uint4 *)(win + x * 256 + lane * 4) = make_uint4(v[x].x, v[x].y, v[x].z, v[x].w);
+#pragma unroll
+            for (int x = 0; x < WT_TC / 256; x++) tcw[x * 64 + lane] = t[x];
+        }
+        __syncthreads();
+        uint32_t gw = uni(win[ptr - rb]);
+        uint32_t W = gw & ROW_W_MASK, n = (W + 15u) >> 4;
+        for (;;) {
+            if ((i | j) == 0u) { done = true; break; }
+            if (ptr - (int32_t)n - 1 < rb || (int32_t)j - 1 < jb) break;          // next refill
+            const uint32_t k = j - lo;
+            if (k >= W || budget-- == 0u) { ok = false; done = true; break; }
+            const int32_t up = ptr - (int32_t)n - 1;                 // meta dword of row i - 1
+            // one LDS round trip for the arrow dword, the meta dword of the row above and the target
+            // code of column j (the last two are only used by some moves)
+            const uint32_t aw_v = win[up + 1 + (int32_t)(k >> 4) - rb], gup_v = win[up - rb];
+            const uint32_t tb_v = tcw8[(int32_t)j - jb];
+            const uint32_t aw = uni(aw_v), gup = uni(gup_v), tbase = uni(tb_v) - 1u;
+            score += (int32_t)uni((uint32_t)pend_v); pend_v = 0;
+            const uint32_t a = (aw >> ((k & 15u) * 2u)) & 3u;
+            const uint32_t mv = a == 0u ? 0u : a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : 4u;
+            if (mv == 4u || (i == 0u && mv != 2u) || (j == 0u && mv != 1u)) { ok = false; done = true; break; }
+            if (mv == 0u) {
+                const uint32_t qb = (gw >> 10) & 7u;
+                nM += qb == tbase ? 1u : 0u;
+                pend_v = sub[qb * 5 + tbase];         // added one step later: keeps the LDS read off the critical path
+                run++; ndiag++; prev_op = 0;
+            } else {
+                if (run) {
+                    outp -= 3;
+                    if (lane == 0) { outp[0] = i; outp[1] = j; outp[2] = run; }
+                    nb++; run = 0;
+                }
+                nopen += prev_op != mv ? 1u : 0u;
+                prev_op = mv;
+            }
+            if (mv != 1u) j--;
+            if (mv != 2u) {
+                i--;
+                lo -= (gw >> 13) & 1023u;
+                ptr = up;
+                gw = gup;
+                W = gw & ROW_W_MASK; n = (W + 15u) >> 4;
+            }
+        }
+    }
+    score += (int32_t)uni((uint32_t)pend_v);
+    if (run) { outp -= 3; if (lane == 0) { outp[0] = i; outp[1] = j; outp[2] = run; } nb++; }
+    if (lane != 0) return;
+    gba_pair_result &R = res[p];
+    if (!ok) { d.status[p] = GBA_PAIR_UNREACHABLE; return; }
     const uint32_t nI = Q - ndiag, nD = T - ndiag;
     if (tc_.affine) score += (int32_t)nopen * tc_.aopen + (int32_t)(nI + nD) * tc_.aext;
     else score += (int32_t)nI * tc_.ins + (int32_t)nD * tc_.del;
@@ -1194,9 +1300,14 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (pl.n_ok)
     {
-        const dim3 grid((pl.n_ok + TB_LANES - 1) / TB_LANES), block(TB_LANES);
-        if (sc.mode == GBA_MODE_AFFINE) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, s, d, c->tbc, res);
-        else hipLaunchKernelGGL(k_traceback<false>, grid, block, 0, s, d, c->tbc, res);
+        const bool aff = sc.mode == GBA_MODE_AFFINE;
+        const uint32_t n_wide = aff ? 0u : pl.cls_count[CLS_WIDE], n_lane = pl.n_ok - n_wide;
+        const dim3 grid((n_lane + TB_LANES - 1) / TB_LANES), block(TB_LANES);
+        if (n_wide) hipLaunchKernelGGL(k_traceback_wide, dim3(n_wide), dim3(64), 0, s, d, c->tbc, res);
+        if (n_lane) {
+            if (aff) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, s, d, c->tbc, res, n_lane);
+            else hipLaunchKernelGGL(k_traceback<false>, grid, block, 0, s, d, c->tbc, res, n_lane);
+        }
     }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
     hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, s, d, res, out->blocks_capacity, (uint64_t *)c->b_needed.ptr);
