@@ -727,7 +727,8 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
 // compared word) and records are exactly those of k_fill.
 //
 // Guide words are staged through an LDS ring of the wave, refilled 64 words at a time.
-constexpr int WIDE_RING = 2048 + 64;          // shift + width <= 2046, lanes run up to 63 columns past the row end
+constexpr int WIDE_NB = 4;                   // chunks of 64 columns in flight
+constexpr int WIDE_RING = 2048 + 64 * WIDE_NB;          // shift + width <= 2046, lanes run up to 63 columns past the row end
 constexpr int WIDE_SBUF = 512;                // guide words buffered per wave (a row has at most 1 + 128)
 
 __device__ __forceinline__ int32_t wave_scan_min(int32_t v, int32_t identity)
@@ -793,33 +794,44 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc)
         uint32_t cdiag = dsh >= 1u && dsh - 1u < Wp ? ring[dsh - 1u] : INFW;
         int32_t hc = r == 0 ? -D : (int32_t)INFW;       // row 0: column j costs j deletions
         const uint32_t nd = (W + 15u) >> 4;
-        for (uint32_t c0 = 0; c0 < W; c0 += 64) {
-            const uint32_t k = c0 + lane;
-            const uint32_t up = ring[k + dsh];
-            const uint32_t diag = (uint32_t)__builtin_amdgcn_update_dpp((int32_t)cdiag, (int32_t)up, 0x138, 0xf, 0xf, false);
-            cdiag = (uint32_t)__builtin_amdgcn_readlane((int32_t)up, 63);
-            const uint32_t tcd = up & 7u;
-            const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);
-            const int32_t m = (int32_t)((sb << 5) + diag);
-            const int32_t u = (int32_t)up + fc.cU;
-            const int32_t xv = min(m, u);                               // best of the two moves from the previous row
-            const int32_t a = (int32_t)((uint32_t)xv & ~TAGS) - lane * D;
-            const int32_t incl = wave_scan_min(a, BIG);
-            const int32_t excl = __builtin_amdgcn_update_dpp(BIG, incl, 0x138, 0xf, 0xf, false);
-            const int32_t lc = min(excl + lane * D, hc + (lane + 1) * D) + codeL;
-            __syncthreads();                                            // every lane has read its slots before any is overwritten
-            const uint32_t best = (uint32_t)min(xv, lc);
-            const uint32_t cw = (up & TAGS) | (best & ~TAGS);
-            ring[k] = cw;
-            hc = __builtin_amdgcn_readlane((int32_t)(best & ~TAGS), 63);
-            // arrows: 2 bits per column, 16 columns per dword
-            int32_t ab = (int32_t)(((best >> 3) & 3u) << (2 * (lane & 15)));
-            ab |= __builtin_amdgcn_update_dpp(0, ab, 0x111, 0xf, 0xf, false);
-            ab |= __builtin_amdgcn_update_dpp(0, ab, 0x112, 0xf, 0xf, false);
-            ab |= __builtin_amdgcn_update_dpp(0, ab, 0x114, 0xf, 0xf, false);
-            ab |= __builtin_amdgcn_update_dpp(0, ab, 0x118, 0xf, 0xf, false);
-            const uint32_t dwi = (c0 >> 4) + ((uint32_t)lane >> 4);
-            if ((lane & 15) == 15 && dwi < nd) rec[roff + dwi] = (uint32_t)ab;
+        // WIDE_NB chunks of 64 columns at a time: their loads, candidate words and local scans are
+        // independent of each other; only the carries (scalar) link a chunk to the one before it
+        for (uint32_t c0 = 0; c0 < W; c0 += 64 * WIDE_NB) {
+            uint32_t up[WIDE_NB];
+            int32_t xv[WIDE_NB], incl[WIDE_NB];
+#pragma unroll
+            for (int b = 0; b < WIDE_NB; b++) up[b] = ring[c0 + 64 * b + lane + dsh];     // past the row end: slots that exist, values nobody uses
+            __syncthreads();                            // every lane has read its slots before any is overwritten
+#pragma unroll
+            for (int b = 0; b < WIDE_NB; b++) {
+                const uint32_t diag = (uint32_t)__builtin_amdgcn_update_dpp((int32_t)cdiag, (int32_t)up[b], 0x138, 0xf, 0xf, false);
+                cdiag = (uint32_t)__builtin_amdgcn_readlane((int32_t)up[b], 63);
+                const uint32_t tcd = up[b] & 7u;
+                const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);
+                const int32_t m = (int32_t)((sb << 5) + diag);
+                const int32_t u = (int32_t)up[b] + fc.cU;
+                xv[b] = min(m, u);                      // best of the two moves from the previous row
+                incl[b] = wave_scan_min((int32_t)((uint32_t)xv[b] & ~TAGS) - lane * D, BIG);
+            }
+#pragma unroll
+            for (int b = 0; b < WIDE_NB; b++) {
+                if (c0 + 64 * b < W) {
+                    const int32_t excl = __builtin_amdgcn_update_dpp(BIG, incl[b], 0x138, 0xf, 0xf, false);
+                    const int32_t lc = min(excl + lane * D, hc + (lane + 1) * D) + codeL;
+                    const uint32_t best = (uint32_t)min(xv[b], lc);
+                    ring[c0 + 64 * b + lane] = (up[b] & TAGS) | (best & ~TAGS);
+                    // score of the chunk's last column: its own best over this chunk's columns, or the carry
+                    hc = min(__builtin_amdgcn_readlane(incl[b], 63) + 63 * D, hc + 64 * D);
+                    // arrows: 2 bits per column, 16 columns per dword
+                    int32_t ab = (int32_t)(((best >> 3) & 3u) << (2 * (lane & 15)));
+                    ab |= __builtin_amdgcn_update_dpp(0, ab, 0x111, 0xf, 0xf, false);
+                    ab |= __builtin_amdgcn_update_dpp(0, ab, 0x112, 0xf, 0xf, false);
+                    ab |= __builtin_amdgcn_update_dpp(0, ab, 0x114, 0xf, 0xf, false);
+                    ab |= __builtin_amdgcn_update_dpp(0, ab, 0x118, 0xf, 0xf, false);
+                    const uint32_t dwi = ((c0 + 64 * b) >> 4) + ((uint32_t)lane >> 4);
+                    if ((lane & 15) == 15 && dwi < nd) rec[roff + dwi] = (uint32_t)ab;
+                }
+            }
         }
         if (lane == 0) rec[roff + nd] = word & ROW_META_MASK;
         roff += nd + 1u;
