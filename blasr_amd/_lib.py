@@ -51,6 +51,7 @@ class Batch(C.Structure):
         ("t_arena", C.c_void_p), ("t_off", C.c_void_p), ("t_len", C.c_void_p),
         ("blocks", C.c_void_p), ("blk_off", C.c_void_p), ("n_blk", C.c_void_p),
         ("q_arena_bytes", C.c_uint64), ("t_arena_bytes", C.c_uint64), ("n_blocks_total", C.c_uint64),
+        ("t_rc", C.c_void_p),
     ]
 
 
@@ -66,7 +67,7 @@ class Timing(C.Structure):
 
 
 EXPORTS = ("gba_create", "gba_destroy", "gba_set_scoring", "gba_submit", "gba_wait",
-           "gba_submit_device", "gba_get_timing", "gba_last_hip_error", "gba_strerror", "gba_version")
+           "gba_submit_device", "gba_set_reference", "gba_get_timing", "gba_last_hip_error", "gba_strerror", "gba_version")
 
 _lib = None
 
@@ -93,6 +94,7 @@ def lib():
         L.gba_submit.argtypes = [C.c_void_p, C.POINTER(Batch)]
         L.gba_wait.argtypes = [C.c_void_p, C.POINTER(Results)]
         L.gba_submit_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Results)]
+        L.gba_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.gba_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         L.gba_last_hip_error.argtypes = [C.c_void_p]
         L.gba_strerror.argtypes = [C.c_int]

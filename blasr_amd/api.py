@@ -73,6 +73,15 @@ class Context:
         self._check(self._L.gba_set_scoring(self._h, C.byref(scoring)))
         self.scoring = scoring
 
+    def set_reference(self, ref):
+        """Keep `ref` (bytes / uint8 array, the genome as ASCII) in device memory; batches without a
+        "t_arena" then describe their targets as windows of it (t_off, t_len, optional t_rc)."""
+        if ref is None or len(ref) == 0:
+            self._check(self._L.gba_set_reference(self._h, None, 0))
+            return
+        a = np.ascontiguousarray(np.frombuffer(ref, dtype=np.uint8) if isinstance(ref, (bytes, bytearray)) else ref, dtype=np.uint8)
+        self._check(self._L.gba_set_reference(self._h, _ptr(a), a.size))
+
     def timing(self):
         t = Timing()
         self._check(self._L.gba_get_timing(self._h, C.byref(t)))
@@ -86,11 +95,14 @@ class Context:
         keep = {k: np.ascontiguousarray(batch[k], dtype=dt) for k, dt in (
             ("q_arena", np.uint8), ("t_arena", np.uint8), ("blocks", BLOCK_DT),
             ("q_off", np.uint64), ("t_off", np.uint64), ("blk_off", np.uint64),
-            ("q_len", np.uint32), ("t_len", np.uint32), ("n_blk", np.uint32))}
+            ("q_len", np.uint32), ("t_len", np.uint32), ("n_blk", np.uint32), ("t_rc", np.uint8))
+            if batch.get(k) is not None}
+        ta = keep.get("t_arena")          # absent: windows of the reference given to set_reference
         b = Batch(n, _ptr(keep["q_arena"]), _ptr(keep["q_off"]), _ptr(keep["q_len"]),
-                  _ptr(keep["t_arena"]), _ptr(keep["t_off"]), _ptr(keep["t_len"]),
+                  _ptr(ta) if ta is not None else None, _ptr(keep["t_off"]), _ptr(keep["t_len"]),
                   _ptr(keep["blocks"]), _ptr(keep["blk_off"]), _ptr(keep["n_blk"]),
-                  keep["q_arena"].size, keep["t_arena"].size, keep["blocks"].size)
+                  keep["q_arena"].size, ta.size if ta is not None else 0, keep["blocks"].size,
+                  _ptr(keep["t_rc"]) if "t_rc" in keep else None)
         self._check(self._L.gba_submit(self._h, C.byref(b)))
         if blocks_capacity is None:
             blocks_capacity = int(keep["q_len"].astype(np.uint64).sum()) + n
@@ -108,10 +120,13 @@ class Context:
         an int32 tensor [n_blocks, 3]).  out_pairs: uint8 tensor of n*PAIR_RESULT_DT.itemsize
         bytes; out_blocks: int32 tensor [capacity, 3].  Returns (rc, blocks_needed)."""
         n = int(dbatch["n_pairs"])
+        ta = dbatch.get("t_arena")
+        trc = dbatch.get("t_rc")
         b = Batch(n, dbatch["q_arena"].data_ptr(), dbatch["q_off"].data_ptr(), dbatch["q_len"].data_ptr(),
-                  dbatch["t_arena"].data_ptr(), dbatch["t_off"].data_ptr(), dbatch["t_len"].data_ptr(),
+                  ta.data_ptr() if ta is not None else None, dbatch["t_off"].data_ptr(), dbatch["t_len"].data_ptr(),
                   dbatch["blocks"].data_ptr(), dbatch["blk_off"].data_ptr(), dbatch["n_blk"].data_ptr(),
-                  dbatch["q_arena"].numel(), dbatch["t_arena"].numel(), dbatch["blocks"].shape[0])
+                  dbatch["q_arena"].numel(), ta.numel() if ta is not None else 0, dbatch["blocks"].shape[0],
+                  trc.data_ptr() if trc is not None else None)
         assert out_pairs.numel() * out_pairs.element_size() >= n * PAIR_RESULT_DT.itemsize
         r = Results(out_pairs.data_ptr(), out_blocks.data_ptr(), out_blocks.shape[0], 0)
         rc = self._check(self._L.gba_submit_device(self._h, C.byref(b), C.byref(r)), allow=(_lib.E_NOSPACE,))
@@ -122,8 +137,9 @@ def to_device(batch, device="cuda:0"):
     """Copy a host batch dict to torch CUDA tensors (bit patterns preserved)."""
     import torch
     d = {"n_pairs": int(batch["n_pairs"])}
-    for k in ("q_arena", "t_arena"):
-        d[k] = torch.from_numpy(np.ascontiguousarray(batch[k], dtype=np.uint8)).to(device)
+    for k in ("q_arena", "t_arena", "t_rc"):
+        if batch.get(k) is not None:
+            d[k] = torch.from_numpy(np.ascontiguousarray(batch[k], dtype=np.uint8)).to(device)
     for k in ("q_off", "t_off", "blk_off"):
         d[k] = torch.from_numpy(np.ascontiguousarray(batch[k], dtype=np.uint64).view(np.int64)).to(device)
     for k in ("q_len", "t_len", "n_blk"):

@@ -75,7 +75,8 @@ struct Plan {                 // device -> host after k_scan3 / k_plan
 struct Dev {                  // per-batch device state, SoA per pair
     uint32_t n;
     // inputs (device pointers)
-    const uint8_t *q_arena, *t_arena;
+    const uint8_t *q_arena, *t_arena, *t_rc;
+    uint64_t t_arena_bytes;   // extent of t_arena when it is the ctx reference (windows are checked against it), else 0
     const uint64_t *q_off, *t_off, *blk_off;
     const uint32_t *q_len, *t_len, *n_blk;
     const gba_block *blocks;
@@ -132,6 +133,7 @@ __global__ void k_meta(Dev d, int mode, int kband_k)
     uint64_t drift_sum = 0;
     const uint32_t ql = d.q_len[p], tl = d.t_len[p];
     uint32_t nb = 0;
+    if (d.t_arena_bytes && d.t_off[p] + tl > d.t_arena_bytes) st = GBA_PAIR_BAD_GUIDE;     // window outside the reference
     if (mode == GBA_MODE_KBAND) {
         Q = ql; T = tl;
         int64_t dd = (int64_t)tl - (int64_t)ql;
@@ -237,11 +239,20 @@ __global__ __launch_bounds__(256) void k_pack(Dev d)
     uint8_t *qc = d.qcodes + qc_offset(d, p);
     uint8_t *tc = d.tcodes + tc_offset(d, p);
     const uint8_t *q = d.q_arena + d.q_off[p] + d.qS[p];
-    const uint8_t *t = d.t_arena + d.t_off[p] + d.tS[p];
+    const bool rc = d.t_rc != nullptr && d.t_rc[p] != 0;
+    // forward: column j is slice byte tS + j - 1; reverse complement: the slice read backwards from
+    // its last byte, bases complemented (A<->T, C<->G, N stays)
+    const uint8_t *t = d.t_arena + d.t_off[p] + (rc ? (uint64_t)d.t_len[p] - d.tS[p] : (uint64_t)d.tS[p]);
     for (uint32_t i = threadIdx.x; i <= Q + 16; i += blockDim.x)
         qc[i] = (i >= 1 && i <= Q) ? (uint8_t)base_code(q[i - 1]) : (uint8_t)4;
-    for (uint32_t j = threadIdx.x; j <= T + 16; j += blockDim.x)
-        tc[j] = (j >= 1 && j <= T) ? (uint8_t)(base_code(t[j - 1]) + 1u) : (uint8_t)5;
+    for (uint32_t j = threadIdx.x; j <= T + 16; j += blockDim.x) {
+        uint32_t code = 4u;
+        if (j >= 1 && j <= T) {
+            if (rc) { const uint32_t f = base_code(*(t - j)); code = f < 4u ? 3u - f : 4u; }
+            else code = base_code(t[j - 1]);
+        }
+        tc[j] = (uint8_t)(code + 1u);
+    }
 }
 
 // ---------------------------------------------------------------- k_guide
@@ -1155,6 +1166,9 @@ struct gba_ctx {
     FillConst fc;
     TbConst tbc;
     // device scratch (grow-only)
+    Buf b_ref;                       // reference for batches without a target arena (gba_set_reference)
+    uint64_t ref_len = 0;
+    Buf s_trc;
     Buf b_pair32[14], b_pair64[5], b_dp, b_plan, b_guide, b_qc, b_tc, b_rec, b_blk, b_needed;
     // staging for the host-pointer path
     Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res, s_out;
@@ -1231,6 +1245,11 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     memset(&d, 0, sizeof(d));
     d.n = n;
     d.q_arena = b->q_arena; d.t_arena = b->t_arena; d.blocks = b->blocks;
+    d.t_rc = b->t_rc;
+    if (!d.t_arena) {            // targets are windows of the ctx reference
+        if (!c->b_ref.ptr) return GBA_E_STATE;
+        d.t_arena = (const uint8_t *)c->b_ref.ptr; d.t_arena_bytes = c->ref_len;
+    }
     d.q_off = b->q_off; d.t_off = b->t_off; d.blk_off = b->blk_off;
     d.q_len = b->q_len; d.t_len = b->t_len; d.n_blk = b->n_blk;
     d.status = (int32_t *)c->b_pair32[0].ptr;
@@ -1403,7 +1422,7 @@ void gba_destroy(gba_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &b : c->b_pair32) release(b);
     for (auto &b : c->b_pair64) release(b);
-    Buf *bs[] = {&c->b_dp, &c->b_plan, &c->b_guide, &c->b_qc, &c->b_tc, &c->b_rec, &c->b_blk, &c->b_needed,
+    Buf *bs[] = {&c->b_ref, &c->s_trc, &c->b_dp, &c->b_plan, &c->b_guide, &c->b_qc, &c->b_tc, &c->b_rec, &c->b_blk, &c->b_needed,
                  &c->s_q, &c->s_t, &c->s_blk, &c->s_qoff, &c->s_toff, &c->s_boff, &c->s_qlen, &c->s_tlen,
                  &c->s_nblk, &c->s_res, &c->s_out};
     for (Buf *b : bs) release(*b);
@@ -1493,6 +1512,7 @@ int gba_submit(gba_ctx *c, const gba_batch *b)
         {&c->s_blk, b->blocks, (size_t)b->n_blocks_total * sizeof(gba_block)},
         {&c->s_qoff, b->q_off, (size_t)n * 8}, {&c->s_toff, b->t_off, (size_t)n * 8}, {&c->s_boff, b->blk_off, (size_t)n * 8},
         {&c->s_qlen, b->q_len, (size_t)n * 4}, {&c->s_tlen, b->t_len, (size_t)n * 4}, {&c->s_nblk, b->n_blk, (size_t)n * 4}};
+    if (!b->t_arena) { cp[1].src = nullptr; cp[1].bytes = 0; }      // windows of the ctx reference: nothing to stage
     for (auto &x : cp) {
         if ((rc = ensure(c, *x.buf, x.bytes + 16))) return rc;
         if (x.bytes) HIPCHK(c, hipMemcpyAsync(x.buf->ptr, x.src, x.bytes, hipMemcpyHostToDevice, c->stream));
@@ -1503,7 +1523,12 @@ int gba_submit(gba_ctx *c, const gba_batch *b)
     if ((rc = ensure(c, c->s_res, (size_t)n * sizeof(gba_pair_result)))) return rc;
     if ((rc = ensure(c, c->s_out, (size_t)cap * sizeof(gba_block)))) return rc;
     gba_batch db = *b;
-    db.q_arena = (const uint8_t *)c->s_q.ptr; db.t_arena = (const uint8_t *)c->s_t.ptr;
+    db.q_arena = (const uint8_t *)c->s_q.ptr; db.t_arena = b->t_arena ? (const uint8_t *)c->s_t.ptr : nullptr;
+    if (b->t_rc) {
+        if ((rc = ensure(c, c->s_trc, (size_t)n + 16))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->s_trc.ptr, b->t_rc, n, hipMemcpyHostToDevice, c->stream));
+        db.t_rc = (const uint8_t *)c->s_trc.ptr;
+    }
     db.blocks = (const gba_block *)c->s_blk.ptr;
     db.q_off = (const uint64_t *)c->s_qoff.ptr; db.t_off = (const uint64_t *)c->s_toff.ptr;
     db.blk_off = (const uint64_t *)c->s_boff.ptr;
@@ -1541,6 +1566,21 @@ int gba_wait(gba_ctx *c, gba_results *out)
         }
         return GBA_E_NOSPACE;
     }
+    return GBA_OK;
+}
+
+int gba_set_reference(gba_ctx *c, const uint8_t *ref, uint64_t len)
+{
+    if (!c || (len && !ref)) return GBA_E_INVALID;
+    if (c->in_flight) return GBA_E_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->ref_len = 0;
+    if (len == 0) { release(c->b_ref); return GBA_OK; }
+    int rc = ensure(c, c->b_ref, (size_t)len + 16);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(c->b_ref.ptr, ref, (size_t)len, hipMemcpyHostToDevice));
+    c->ref_len = len;
     return GBA_OK;
 }
 

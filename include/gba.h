@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GBA_VERSION 100   /* major*10000 + minor*100 + patch */
+#define GBA_VERSION 200   /* major*10000 + minor*100 + patch */
 
 /* return codes of the entry points */
 enum {
@@ -38,12 +38,12 @@ enum {
 enum {
     GBA_PAIR_OK = 0,
     GBA_PAIR_EMPTY_GUIDE = 1,      /* no blocks: candidate left as it was (BlasrUtilsImpl.hpp:681) */
-    GBA_PAIR_BAD_GUIDE = 2,        /* blocks unordered, overlapping, empty or outside the sequences */
+    GBA_PAIR_BAD_GUIDE = 2,        /* blocks unordered, overlapping, empty or outside the sequences; window outside the reference */
     GBA_PAIR_UNREACHABLE = 3,      /* the band is disconnected: no path reaches the end cell */
     GBA_PAIR_NOSPACE = 4,          /* blocks of this pair did not fit the caller's arena */
     GBA_PAIR_END_OUT_OF_BAND = 5,  /* k-band: |t_len - q_len| > k */
-    GBA_PAIR_TOO_WIDE = 6,         /* a band row wider than the kernels support */
-    GBA_PAIR_TOO_LONG = 7          /* more DP rows or columns than the kernels support */
+    GBA_PAIR_TOO_WIDE = 6,         /* a band row wider than the kernels support (linear, k-band: 1023 cells or a shift of 1023; affine: shift + width > 252) */
+    GBA_PAIR_TOO_LONG = 7          /* more DP rows or columns than the kernels support (65535 rows, affine 32767; 2^20 columns) */
 };
 
 enum { GBA_MODE_LINEAR = 0,   /* replaces GuidedAlign,       BlasrUtilsImpl.hpp:713-716, :727-730 */
@@ -93,6 +93,16 @@ typedef struct { uint32_t q_pos, t_pos, length; } gba_block;
  * Pairs may share arena bytes (all candidates of a read view the same query).
  * All pointers are host pointers for gba_submit and device pointers for
  * gba_submit_device.
+ *
+ * Targets as reference windows: with t_arena == NULL the targets are windows of
+ * the reference given to gba_set_reference (resident in device memory): t_off[p]
+ * is the window's start on the forward strand, t_len[p] its length.  t_rc (may
+ * be NULL = all forward) marks the pairs whose target is the REVERSE COMPLEMENT
+ * of its arena / reference slice; the slice is complemented while it is packed
+ * on the device, which replaces the per-candidate window copy
+ * genome.Copy / genome.CopyAsRC of iblasr/BlasrAlignImpl.hpp:727-743.  Guide
+ * blocks and results are in the coordinates of the target as the aligner sees it
+ * (after the reverse complement), exactly as for an explicit arena.
  */
 typedef struct {
     uint32_t n_pairs;
@@ -100,6 +110,7 @@ typedef struct {
     const uint8_t *t_arena; const uint64_t *t_off; const uint32_t *t_len;
     const gba_block *blocks; const uint64_t *blk_off; const uint32_t *n_blk;
     uint64_t q_arena_bytes, t_arena_bytes, n_blocks_total;   /* extents of the three arenas */
+    const uint8_t *t_rc;        /* per pair, nonzero: target = reverse complement of its slice; NULL: none */
 } gba_batch;
 
 /* what RefineAlignment copies back into the candidate (BlasrUtilsImpl.hpp:745-772) */
@@ -153,6 +164,11 @@ int gba_wait(gba_ctx *ctx, gba_results *out);
  * memory (all pointers in `dev_batch` and `dev_out` are device pointers).
  * Returns when the batch has completed; out->blocks_needed is filled in. */
 int gba_submit_device(gba_ctx *ctx, const gba_batch *dev_batch, gba_results *dev_out);
+
+/* Keeps a copy of the reference (genome, ASCII; `ref` is a host pointer) in device
+ * memory for batches whose t_arena is NULL; len == 0 drops it.  Replaces the
+ * per-candidate window copies out of the genome, iblasr/BlasrAlignImpl.hpp:727-743. */
+int gba_set_reference(gba_ctx *ctx, const uint8_t *ref, uint64_t len);
 
 int gba_get_timing(gba_ctx *ctx, gba_timing *t);
 int gba_last_hip_error(gba_ctx *ctx);

@@ -276,3 +276,59 @@ def test_full_size_properties(ctx, api, oracle, synth):
     for p in range(24):
         for f in util.FIELDS:
             assert int(ores[p][f]) == int(pairs[p][f]), (f, p)
+
+
+_COMP = np.full(256, ord("N"), dtype=np.uint8)
+for _a, _b in zip(b"ACGTacgt", b"TGCAtgca"):
+    _COMP[_a] = _b
+
+
+def test_reference_windows_and_reverse_complement(ctx, api, oracle, synth):
+    """Targets given as windows of a reference resident in device memory, half of them on the
+    reverse strand (the reference's genome.Copy / CopyAsRC, iblasr/BlasrAlignImpl.hpp:727-743):
+    same results as the same targets spelled out in an arena, which the oracle checks."""
+    from blasr_amd import _lib
+    n = 96
+    batch = synth.generate(n, read_len=1800, len_jitter=900, seed=77)
+    # build a "genome": the pairs' targets laid end to end with spacers, odd pairs stored as the
+    # reverse complement of what the aligner must see
+    pieces, t_off, t_rc, pos = [], np.zeros(n, np.uint64), np.zeros(n, np.uint8), 0
+    for p in range(n):
+        t = np.asarray(batch["t_arena"][int(batch["t_off"][p]):int(batch["t_off"][p]) + int(batch["t_len"][p])])
+        if p % 2:
+            t = _COMP[t[::-1]]
+            t_rc[p] = 1
+        spacer = np.frombuffer(b"ACGTN" * 3, dtype=np.uint8)
+        pieces += [spacer, t]
+        pos += spacer.size
+        t_off[p] = pos
+        pos += t.size
+    genome = np.concatenate(pieces)
+    ctx.set_scoring(api.make_scoring())
+    want, wblk, rc = ctx.refine_host(batch)
+    assert rc == 0
+    util.compare_batch(oracle, batch, oracle.make_params(), want, wblk, None)
+    ctx.set_reference(genome)
+    wb = {k: batch[k] for k in ("n_pairs", "q_arena", "q_off", "q_len", "t_len", "blocks", "blk_off", "n_blk")}
+    wb["t_off"] = t_off
+    wb["t_rc"] = t_rc
+    got, gblk, rc = ctx.refine_host(wb)
+    assert rc == 0
+    assert np.array_equal(got, want) and np.array_equal(gblk, wblk)
+    # a window that leaves the reference is refused for that pair only
+    bad = dict(wb)
+    bad["t_off"] = t_off.copy()
+    bad["t_off"][5] = genome.size - 10
+    got2, _, rc = ctx.refine_host(bad)
+    assert rc == 0 and int(got2[5]["status"]) == _lib.PAIR_BAD_GUIDE and int(got2[6]["status"]) == 0
+    # device-resident batch against the same reference
+    import torch
+    d = api.to_device(wb)
+    out_pairs = torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0")
+    out_blocks = torch.zeros((len(wblk) + 8, 3), dtype=torch.int32, device="cuda:0")
+    rc, needed = ctx.refine_device(d, out_pairs, out_blocks)
+    assert rc == 0 and needed == len(wblk)
+    assert np.array_equal(out_pairs.cpu().numpy().view(_lib.PAIR_RESULT_DT), want)
+    ctx.set_reference(None)
+    with pytest.raises(Exception):
+        ctx.refine_host(wb)          # no reference, no arena: call out of sequence
