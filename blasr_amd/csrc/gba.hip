@@ -911,7 +911,8 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
         const bool active = live && ok && (i | j) != 0u;
         if (!__any(active)) break;
         {
-            const int32_t look = (int32_t)min(n + 1u, (uint32_t)TB_RW - 1u);
+            // linear pairs of the lane classes have rows of at most 8 arrow dwords: always inside the window
+            const int32_t look = AFF ? (int32_t)min(n + 1u, (uint32_t)TB_RW - 1u) : (int32_t)n + 1;
             if (__any(active && (ptr - look < rb || (int32_t)(j >> 2) - 1 < tb))) {
                 if (active) {
                     rb = ptr - (TB_RW - 1);
@@ -942,8 +943,8 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
             const int32_t at = ptr - (int32_t)(n - (kc >> CSHIFT));     // dword holding cell k
             const int32_t up = ptr - (int32_t)n - 1;                    // meta dword of row i - 1
             uint32_t aw, gup;
-            if (at < rb) aw = rec[at]; else aw = rwin[(at - rb) * TB_LANES + lane];    // rows wider than the window
-            if (up < rb) gup = rec[up]; else gup = rwin[(up - rb) * TB_LANES + lane];
+            if (AFF && at < rb) aw = rec[at]; else aw = rwin[(at - rb) * TB_LANES + lane];    // affine rows can be wider than the window
+            if (AFF && up < rb) gup = rec[up]; else gup = rwin[(up - rb) * TB_LANES + lane];
             const uint32_t tbase = (uint32_t)twin8[(((j >> 2) - (uint32_t)tb) * TB_LANES + lane) * 4 + (j & 3u)] - 1u;
             score += pend; pend = 0;
             const uint32_t cell = aw >> ((kc & CMASK) * BITS);
@@ -1334,10 +1335,17 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
         const bool aff = sc.mode == GBA_MODE_AFFINE;
         const uint32_t n_wide = aff ? 0u : pl.cls_count[CLS_WIDE], n_lane = pl.n_ok - n_wide;
         const dim3 grid((n_lane + TB_LANES - 1) / TB_LANES), block(TB_LANES);
-        if (n_wide) hipLaunchKernelGGL(k_traceback_wide, dim3(n_wide), dim3(64), 0, s, d, c->tbc, res);
+        // the two tracebacks work on disjoint pairs: the wave-per-pair one runs beside the other
+        if (n_wide) {
+            hipStream_t ws = n_lane ? c->aux[0] : s;
+            if (n_lane) { HIPCHK(c, hipEventRecord(c->ev_fork, s)); HIPCHK(c, hipStreamWaitEvent(ws, c->ev_fork, 0)); }
+            hipLaunchKernelGGL(k_traceback_wide, dim3(n_wide), dim3(64), 0, ws, d, c->tbc, res);
+            if (n_lane) HIPCHK(c, hipEventRecord(c->ev_join[0], ws));
+        }
         if (n_lane) {
             if (aff) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, s, d, c->tbc, res, n_lane);
             else hipLaunchKernelGGL(k_traceback<false>, grid, block, 0, s, d, c->tbc, res, n_lane);
+            if (n_wide) HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[0], 0));
         }
     }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
