@@ -40,7 +40,6 @@ typedef uint32_t u32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
 constexpr uint32_t INFW = 0x40000000u;       // "no path" cell word
 constexpr int32_t UNREACH = 0x20000000;      // unbiased words at or above this are unreachable
-constexpr int32_t BIASW = 128 << 5;          // per-row bias of the byte substitution table
 constexpr uint32_t MAX_ROWS = 65535;         // keeps biased words inside int32 (see gba_set_scoring)
 constexpr uint32_t MAX_ROWS_AFFINE = 32767;  // affine words carry one more tag bit
 constexpr uint32_t MAX_COLS = 1u << 20;
@@ -88,7 +87,7 @@ struct Dev {                  // per-batch device state, SoA per pair
     Plan *plan;
     // arenas
     uint32_t *stream;         // guide stream words
-    uint8_t *qcodes, *tcodes;
+    uint8_t *tcodes;
     uint32_t *rec;            // traceback records, per DP row: ceil(width/16) dwords of 2-bit arrows, then one meta dword
     gba_block *blk_scratch;
 };
@@ -117,7 +116,6 @@ __device__ __forceinline__ uint32_t base_code(uint8_t c)
 
 __device__ __forceinline__ uint64_t align16(uint64_t x) { return (x + 15) & ~uint64_t(15); }
 // code arrays of a pair start 16-byte aligned and are followed by at least 17 spare bytes
-__device__ __forceinline__ uint64_t qc_offset(const Dev &d, uint32_t p) { return align16(d.row_off[p] + 32ull * p); }
 __device__ __forceinline__ uint64_t tc_offset(const Dev &d, uint32_t p) { return align16(d.col_off[p] + 32ull * p); }
 
 // ---------------------------------------------------------------- k_meta
@@ -228,23 +226,19 @@ __global__ __launch_bounds__(1024) void k_scan3(Dev d)
 }
 
 // ---------------------------------------------------------------- k_pack
-// qc[i] = code (0..4) of the query base of DP row i (1..Q); tc[j] = code + 1 (1..5) of the target
-// base of DP column j (1..T), the form the fill kernel's byte-table lookup takes; index 0 and the
-// 16 bytes past the end hold N.
+// tc[j] = code + 1 (1..5) of the target base of DP column j (1..T), the form the fill kernels'
+// byte-table lookup takes; index 0 and the 16 bytes past the end hold N.  (Query bases are coded
+// where they are used, in k_guide.)
 __global__ __launch_bounds__(256) void k_pack(Dev d)
 {
     const uint32_t p = blockIdx.x;
     if (d.status[p] != GBA_PAIR_OK) return;
-    const uint32_t Q = d.Q[p], T = d.T[p];
-    uint8_t *qc = d.qcodes + qc_offset(d, p);
+    const uint32_t T = d.T[p];
     uint8_t *tc = d.tcodes + tc_offset(d, p);
-    const uint8_t *q = d.q_arena + d.q_off[p] + d.qS[p];
     const bool rc = d.t_rc != nullptr && d.t_rc[p] != 0;
     // forward: column j is slice byte tS + j - 1; reverse complement: the slice read backwards from
     // its last byte, bases complemented (A<->T, C<->G, N stays)
     const uint8_t *t = d.t_arena + d.t_off[p] + (rc ? (uint64_t)d.t_len[p] - d.tS[p] : (uint64_t)d.tS[p]);
-    for (uint32_t i = threadIdx.x; i <= Q + 16; i += blockDim.x)
-        qc[i] = (i >= 1 && i <= Q) ? (uint8_t)base_code(q[i - 1]) : (uint8_t)4;
     for (uint32_t j = threadIdx.x; j <= T + 16; j += blockDim.x) {
         uint32_t code = 4u;
         if (j >= 1 && j <= T) {
@@ -323,7 +317,7 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
     const uint32_t Q = d.Q[p], T = d.T[p], tS = d.tS[p], qS = d.qS[p];
     uint32_t *g = d.stream + d.word_off[p];
     const uint32_t wcap = d.wcap[p];
-    const uint8_t *qc = d.qcodes + qc_offset(d, p);
+    const uint8_t *qa = d.q_arena + d.q_off[p] + qS;        // query base of DP row r is qa[r - 1]
     const uint8_t *tc = d.tcodes + tc_offset(d, p);
     const uint32_t B = (uint32_t)(guided ? min(band, max_band) : kband_k);
     const uint32_t wfirst = max((uint32_t)max_band, B);
@@ -399,7 +393,7 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
             span = max(span, dl + W);
             recdw += 1u + (mode == GBA_MODE_AFFINE ? (W + 3u) >> 2 : (W + 15u) >> 4);
             if (dl > 1023u || W > 1023u) wide = true;
-            uint32_t word = (W & ROW_W_MASK) | ((uint32_t)qc[r] << 10) | ((dl & 1023u) << 13);
+            uint32_t word = (W & ROW_W_MASK) | ((r > 0u ? base_code(qa[r - 1u]) : 4u) << 10) | ((dl & 1023u) << 13);
             if (nnew > 0u) word |= (uint32_t)tc[cnew] << 23;
             if (nnew > 1u) word |= (uint32_t)tc[cnew + 1u] << 26;
             if (nnew > 2u) word |= (uint32_t)tc[cnew + 2u] << 29;
@@ -1170,7 +1164,7 @@ struct gba_ctx {
     Buf b_ref;                       // reference for batches without a target arena (gba_set_reference)
     uint64_t ref_len = 0;
     Buf s_trc;
-    Buf b_pair32[14], b_pair64[5], b_dp, b_plan, b_guide, b_qc, b_tc, b_rec, b_blk, b_needed;
+    Buf b_pair32[14], b_pair64[5], b_dp, b_plan, b_guide, b_tc, b_rec, b_blk, b_needed;
     // staging for the host-pointer path
     Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res, s_out;
     Plan *h_plan = nullptr;          // pinned
@@ -1278,11 +1272,10 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     HIPCHK(c, hipStreamSynchronize(s));
     const uint64_t rows = c->h_plan->total_rows, cols = c->h_plan->total_cols;
     { int rc = ensure(c, c->b_guide, (size_t)(c->h_plan->total_words + 16) * 4); if (rc) return rc; }
-    { int rc = ensure(c, c->b_qc, (size_t)(rows + 32ull * n + 64)); if (rc) return rc; }
     { int rc = ensure(c, c->b_tc, (size_t)(cols + 32ull * n + 64 + 2 * ARENA_SLACK)); if (rc) return rc; }
     { int rc = ensure(c, c->b_blk, (size_t)(rows + 4) * sizeof(gba_block)); if (rc) return rc; }
     d.stream = (uint32_t *)c->b_guide.ptr;
-    d.qcodes = (uint8_t *)c->b_qc.ptr; d.tcodes = (uint8_t *)c->b_tc.ptr + ARENA_SLACK;
+    d.tcodes = (uint8_t *)c->b_tc.ptr + ARENA_SLACK;
     d.blk_scratch = (gba_block *)c->b_blk.ptr;
 
     hipLaunchKernelGGL(k_pack, dim3(n), dim3(256), 0, s, d);
@@ -1430,7 +1423,7 @@ void gba_destroy(gba_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &b : c->b_pair32) release(b);
     for (auto &b : c->b_pair64) release(b);
-    Buf *bs[] = {&c->b_ref, &c->s_trc, &c->b_dp, &c->b_plan, &c->b_guide, &c->b_qc, &c->b_tc, &c->b_rec, &c->b_blk, &c->b_needed,
+    Buf *bs[] = {&c->b_ref, &c->s_trc, &c->b_dp, &c->b_plan, &c->b_guide, &c->b_tc, &c->b_rec, &c->b_blk, &c->b_needed,
                  &c->s_q, &c->s_t, &c->s_blk, &c->s_qoff, &c->s_toff, &c->s_boff, &c->s_qlen, &c->s_tlen,
                  &c->s_nblk, &c->s_res, &c->s_out};
     for (Buf *b : bs) release(*b);
