@@ -208,19 +208,27 @@ __global__ __launch_bounds__(1024) void k_scan3(Dev d)
 {
     __shared__ uint64_t sm[17];
     uint64_t carry_r = 0, carry_c = 0, carry_w = 0;
-    for (uint32_t base = 0; base < d.n; base += blockDim.x) {
-        uint32_t p = base + threadIdx.x;
-        const bool in = p < d.n;
-        uint64_t tot;
-        uint64_t e = block_excl_scan(in ? d.rows[p] : 0, sm, &tot);
-        if (in) d.row_off[p] = carry_r + e;
-        carry_r += tot;
-        e = block_excl_scan(in ? d.cols[p] : 0, sm, &tot);
-        if (in) d.col_off[p] = carry_c + e;
-        carry_c += tot;
-        e = block_excl_scan(in ? d.wcap[p] : 0, sm, &tot);
-        if (in) d.word_off[p] = carry_w + e;
-        carry_w += tot;
+    // four consecutive pairs per thread
+    for (uint32_t base = 0; base < d.n; base += 4 * blockDim.x) {
+        uint64_t r[4], c[4], w[4], lr = 0, lc = 0, lw = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const uint32_t p = base + 4 * threadIdx.x + x;
+            const bool in = p < d.n;
+            r[x] = in ? d.rows[p] : 0; c[x] = in ? d.cols[p] : 0; w[x] = in ? d.wcap[p] : 0;
+            lr += r[x]; lc += c[x]; lw += w[x];
+        }
+        uint64_t tr, tc, tw;
+        uint64_t er = carry_r + block_excl_scan(lr, sm, &tr);
+        uint64_t ec = carry_c + block_excl_scan(lc, sm, &tc);
+        uint64_t ew = carry_w + block_excl_scan(lw, sm, &tw);
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const uint32_t p = base + 4 * threadIdx.x + x;
+            if (p < d.n) { d.row_off[p] = er; d.col_off[p] = ec; d.word_off[p] = ew; }
+            er += r[x]; ec += c[x]; ew += w[x];
+        }
+        carry_r += tr; carry_c += tc; carry_w += tw;
     }
     if (threadIdx.x == 0) { d.plan->total_rows = carry_r; d.plan->total_cols = carry_c; d.plan->total_words = carry_w; }
 }
@@ -430,8 +438,8 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
 __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
 {
     __shared__ uint64_t sm[17];
-    __shared__ uint32_t cnt[NCLS + 1], base[NCLS + 1], run[NCLS + 1];
-    if (threadIdx.x <= NCLS) { cnt[threadIdx.x] = 0; run[threadIdx.x] = 0; }
+    __shared__ uint32_t cnt[NCLS + 1], base[NCLS + 1];
+    if (threadIdx.x <= NCLS) cnt[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < d.n; p += blockDim.x) {
         uint32_t c = NCLS;
@@ -453,26 +461,44 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
         d.plan->n_ok = a;
     }
     __syncthreads();
+    // Four consecutive pairs per thread and packed counters: within one iteration (4096 pairs) one
+    // scan carries the counts of the four lane classes (16 bits each), a second one the count of
+    // the wide class (13 bits) with the record dwords above it; totals are carried unpacked.
+    static_assert(NCLS == 5 && CLS_WIDE == 4, "packing of the class counters");
+    uint32_t runc[NCLS] = {0, 0, 0, 0, 0};
     uint64_t carry = 0, cells = 0;
-    for (uint32_t b0 = 0; b0 < d.n; b0 += blockDim.x) {
-        const uint32_t p = b0 + threadIdx.x;
-        const uint32_t c = p < d.n ? d.cls[p] : NCLS;
-        uint64_t tot;
-        for (int k = 0; k < NCLS; k++) {
-            uint64_t e = block_excl_scan(c == (uint32_t)k ? 1 : 0, sm, &tot);
-            if (c == (uint32_t)k) d.order[base[k] + run[k] + (uint32_t)e] = p;
-            __syncthreads();
-            if (threadIdx.x == 0) run[k] += (uint32_t)tot;
-            __syncthreads();
+    for (uint32_t b0 = 0; b0 < d.n; b0 += 4 * blockDim.x) {
+        uint32_t c[4];
+        uint64_t rd[4], la = 0, lb = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const uint32_t p = b0 + 4 * threadIdx.x + x;
+            c[x] = p < d.n ? d.cls[p] : NCLS;
+            rd[x] = c[x] < NCLS ? (uint64_t)d.recdw[p] + 16u : 0;
+            if (c[x] < NCLS) cells += d.ncells[p];
+            la += c[x] < CLS_WIDE ? 1ull << (16 * c[x]) : 0ull;
+            lb += (c[x] == CLS_WIDE ? 1ull : 0ull) + (rd[x] << 13);
         }
-        const uint64_t rd = c < NCLS ? (uint64_t)d.recdw[p] + 16u : 0;
-        uint64_t e = block_excl_scan(rd, sm, &tot);
-        if (p < d.n) d.rec_off[p] = carry + e + 4u;
-        carry += tot;
-        block_excl_scan(c < NCLS ? d.ncells[p] : 0, sm, &tot);
-        cells += tot;
+        uint64_t totA, totB;
+        uint64_t ea = block_excl_scan(la, sm, &totA);
+        uint64_t eb = block_excl_scan(lb, sm, &totB);
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const uint32_t p = b0 + 4 * threadIdx.x + x;
+            if (c[x] < CLS_WIDE) d.order[base[c[x]] + runc[c[x]] + (uint32_t)((ea >> (16 * c[x])) & 0xffffu)] = p;
+            else if (c[x] == CLS_WIDE) d.order[base[CLS_WIDE] + runc[CLS_WIDE] + (uint32_t)(eb & 0x1fffu)] = p;
+            if (p < d.n) d.rec_off[p] = carry + (eb >> 13) + 4u;
+            ea += c[x] < CLS_WIDE ? 1ull << (16 * c[x]) : 0ull;
+            eb += (c[x] == CLS_WIDE ? 1ull : 0ull) + (rd[x] << 13);
+        }
+#pragma unroll
+        for (int k = 0; k < CLS_WIDE; k++) runc[k] += (uint32_t)((totA >> (16 * k)) & 0xffffu);
+        runc[CLS_WIDE] += (uint32_t)(totB & 0x1fffu);
+        carry += totB >> 13;
     }
-    if (threadIdx.x == 0) { d.plan->total_rec_dwords = carry; d.plan->total_cells = cells; }
+    uint64_t tot;
+    block_excl_scan(cells, sm, &tot);
+    if (threadIdx.x == 0) { d.plan->total_rec_dwords = carry; d.plan->total_cells = tot; }
 }
 
 // ---------------------------------------------------------------- k_fill
@@ -1109,21 +1135,34 @@ __global__ __launch_bounds__(1024) void k_scan1(Dev d, gba_pair_result *res, uin
 {
     __shared__ uint64_t sm[17];
     uint64_t carry = 0;
-    for (uint32_t b0 = 0; b0 < d.n; b0 += blockDim.x) {
-        const uint32_t p = b0 + threadIdx.x;
-        const bool ok = p < d.n && d.status[p] == GBA_PAIR_OK;
-        uint64_t v = ok ? res[p].n_blk : 0, tot;
-        uint64_t e = block_excl_scan(v, sm, &tot);
-        if (p < d.n) {
-            gba_pair_result &R = res[p];
-            R.status = d.status[p];
-            R.blk_off = carry + e;
-            if (ok) {
-                R.dp_score = d.dp_score[p];
-                R.q_pos = d.qS[p]; R.t_pos = d.tS[p];
-                R.rows = d.Q[p]; R.cols = d.T[p]; R.ncells = d.ncells[p];
-                if (carry + e + v > capacity) R.status = GBA_PAIR_NOSPACE;
+    // four consecutive pairs per thread
+    for (uint32_t b0 = 0; b0 < d.n; b0 += 4 * blockDim.x) {
+        uint64_t v[4], lv = 0;
+        bool ok[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const uint32_t p = b0 + 4 * threadIdx.x + x;
+            ok[x] = p < d.n && d.status[p] == GBA_PAIR_OK;
+            v[x] = ok[x] ? res[p].n_blk : 0;
+            lv += v[x];
+        }
+        uint64_t tot;
+        uint64_t e = carry + block_excl_scan(lv, sm, &tot);
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const uint32_t p = b0 + 4 * threadIdx.x + x;
+            if (p < d.n) {
+                gba_pair_result &R = res[p];
+                R.status = d.status[p];
+                R.blk_off = e;
+                if (ok[x]) {
+                    R.dp_score = d.dp_score[p];
+                    R.q_pos = d.qS[p]; R.t_pos = d.tS[p];
+                    R.rows = d.Q[p]; R.cols = d.T[p]; R.ncells = d.ncells[p];
+                    if (e + v[x] > capacity) R.status = GBA_PAIR_NOSPACE;
+                }
             }
+            e += v[x];
         }
         carry += tot;
     }
