@@ -981,25 +981,26 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
                 mv = st == 0u ? m0 : st;                                // in a gap state the move is the gap's own
                 state = st == 0u ? s0 : st == 1u ? ((cell & 4u) ? 1u : 0u) : ((cell & 2u) ? 2u : 0u);
             }
-            if (!inband || mv == 4u || (i == 0u && (mv == 0u || mv == 1u)) || (j == 0u && (mv == 0u || mv == 2u))) { ok = false; continue; }
-            if (mv == 0u) {
-                const uint32_t qb = (gw >> 10) & 7u;
-                nM += qb == tbase ? 1u : 0u;
-                pend = sub[qb * 5 + tbase];
-                run++; ndiag++; prev_op = 0;
-            } else if (mv != 3u) {
-                if (run) { outp -= 3; outp[0] = i; outp[1] = j; outp[2] = run; nb++; run = 0; }
-                nopen += prev_op != mv ? 1u : 0u;
-                prev_op = mv;
-            }
-            if (mv == 0u || mv == 2u) j--;
-            if (mv == 0u || mv == 1u) {
-                i--;
-                lo -= (gw >> 13) & 1023u;
-                ptr = up;
-                gw = gup;
-                W = gw & ROW_W_MASK; n = (W + CMASK) >> CSHIFT;
-            }
+            // everything below is selects: one lane's move is another lane's no-op
+            const bool isd = mv == 0u, isu = mv == 1u, isl = mv == 2u;
+            const bool bad = !inband || mv == 4u || (i == 0u && (isd || isu)) || (j == 0u && (isd || isl));
+            const bool dmove = isd && !bad, gmove = (isu || isl) && !bad, rowmove = (isd || isu) && !bad;
+            ok = !bad;
+            const uint32_t qb = (gw >> 10) & 7u;
+            nM += dmove && qb == tbase ? 1u : 0u;
+            pend = sub[qb * 5 + min(tbase, 4u)];                          // only kept for a diagonal move
+            pend = dmove ? pend : 0;
+            ndiag += dmove ? 1u : 0u;
+            if (gmove && run != 0u) { outp -= 3; outp[0] = i; outp[1] = j; outp[2] = run; nb++; }
+            run = dmove ? run + 1u : gmove ? 0u : run;
+            nopen += gmove && prev_op != mv ? 1u : 0u;
+            prev_op = dmove ? 0u : gmove ? mv : prev_op;
+            j -= (isd || isl) && !bad ? 1u : 0u;
+            i -= rowmove ? 1u : 0u;
+            lo -= rowmove ? (gw >> 13) & 1023u : 0u;
+            ptr = rowmove ? up : ptr;
+            gw = rowmove ? gup : gw;
+            W = gw & ROW_W_MASK; n = (W + CMASK) >> CSHIFT;
         }
     }
     score += pend;
