@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Randomised differential test: libgba (GPU, through the C ABI) against the oracle.
+
+Draws random workloads (synthetic reads with random error rates and guide sparsity, and
+adversarial pairs whose guides are random increasing blocks over random sequences) and random
+scoring / band / mode parameters, runs both sides and compares every result field and every block.
+Mismatches are written to gpurun_out/fuzz_fail_<k>.json with everything needed to replay them.
+
+usage: python tools/fuzz_gpu.py [--seconds 120] [--seed 1]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FIELDS = ("status", "dp_score", "score", "q_pos", "t_pos", "n_blk", "n_match", "n_mismatch",
+          "n_ins", "n_del", "rows", "cols", "ncells")
+
+
+def random_scoring(rng, _lib):
+    mode = int(rng.choice([_lib.MODE_LINEAR, _lib.MODE_LINEAR, _lib.MODE_AFFINE, _lib.MODE_KBAND]))
+    kw = dict(mode=mode, tie_break=int(rng.integers(0, 2)))
+    lim = 40 if mode == _lib.MODE_AFFINE else 100
+    kw["match"] = int(rng.integers(-lim, 3))
+    kw["mismatch"] = int(rng.integers(0, lim))
+    kw["n_score"] = int(rng.integers(-5, 8))
+    kw["ins"] = int(rng.integers(0, lim))
+    kw["dele"] = int(rng.integers(0, lim))
+    kw["indel"] = int(rng.integers(0, 12))
+    kw["band"] = int(rng.choice([0, 1, 2, 3, 5, 10, 16, 25, 40, 70, 120, 250, 300]))
+    kw["max_band"] = int(rng.choice([5, 12, 30, 60, 250, 400]))
+    if mode == _lib.MODE_AFFINE:
+        kw["band"] = min(kw["band"], 40)
+        kw["max_band"] = min(kw["max_band"], 60)
+        kw["affine_open"] = int(rng.integers(0, 30))
+        kw["affine_extend"] = int(rng.integers(0, 20))
+    if mode == _lib.MODE_KBAND:
+        kw["kband_k"] = int(rng.choice([0, 1, 4, 15, 60, 200, 500]))
+    if rng.random() < 0.3:
+        kw["stats_affine"] = 1
+        kw["stats_affine_open"] = int(rng.integers(0, 12))
+        kw["stats_affine_extend"] = int(rng.integers(0, 6))
+    return kw
+
+
+def random_synth(rng, synth):
+    n = int(rng.integers(8, 160))
+    read_len = int(rng.choice([40, 150, 600, 1500, 3000, 8000]))
+    return synth.generate(
+        n, read_len=read_len, len_jitter=int(rng.integers(0, read_len // 2 + 1)),
+        p_ins=float(rng.uniform(0, 0.15)), p_del=float(rng.uniform(0, 0.12)), p_sub=float(rng.uniform(0, 0.08)),
+        min_block=int(rng.integers(4, 20)), drop_frac=float(rng.uniform(0, 0.7)),
+        seed=int(rng.integers(1, 1 << 30)), decoy_every=int(rng.choice([0, 0, 3, 10])),
+        n_frac=float(rng.choice([0.0, 0.0, 0.05])), ref_len=200_000)
+
+
+def random_adversarial(rng, util):
+    """Pairs whose guide has nothing to do with the sequences: random increasing blocks."""
+    pairs = []
+    for _ in range(int(rng.integers(4, 64))):
+        ql, tl = int(rng.integers(1, 900)), int(rng.integers(1, 900))
+        q = rng.choice(list(b"ACGTN"), size=ql, p=[0.24, 0.24, 0.24, 0.24, 0.04]).astype(np.uint8).tobytes()
+        t = rng.choice(list(b"ACGTacgtN"), size=tl).astype(np.uint8).tobytes()
+        blocks, qp, tp = [], 0, 0
+        for _b in range(int(rng.integers(0, 12))):
+            qp += int(rng.integers(0, 60)); tp += int(rng.integers(0, 60))
+            ln = int(rng.integers(1, 40))
+            if qp + ln > ql or tp + ln > tl:
+                break
+            blocks.append((qp, tp, ln))
+            qp += ln; tp += ln
+        if rng.random() < 0.05 and len(blocks) > 1:
+            blocks[0], blocks[1] = blocks[1], blocks[0]          # malformed guide
+        pairs.append((q, t, blocks))
+    return util.make_batch(pairs)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    import util
+    from blasr_amd import api, synth, _lib
+    from oracle import oracle
+    rng = np.random.default_rng(args.seed)
+    ctx = api.Context(0)
+    pool = ThreadPoolExecutor(16)
+    t_end = time.time() + args.seconds
+    rounds = pairs_done = fails = unsupported = 0
+    hist = {}
+    modes = {}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    while time.time() < t_end:
+        kw = random_scoring(rng, _lib)
+        batch = random_adversarial(rng, util) if rng.random() < 0.35 else random_synth(rng, synth)
+        n = int(batch["n_pairs"])
+        try:
+            ctx.set_scoring(api.make_scoring(**kw))
+        except api.GbaError as e:
+            if e.code == _lib.E_UNSUPPORTED:
+                unsupported += 1
+                continue
+            raise
+        pairs, blocks, rc = ctx.refine_host(batch)
+        assert rc == 0
+        P = oracle.make_params(**kw)
+        chunk = max(1, n // 16)
+        futs = [pool.submit(oracle.align_batch, batch, P, f, min(chunk, n - f)) for f in range(0, n, chunk)]
+        ores, oblk = [], []
+        for f in futs:
+            r, b = f.result()
+            ores += list(r); oblk += b
+        bad = None
+        for p in range(n):
+            o, k = ores[p], pairs[p]
+            ko = int(k["status"])
+            if ko in (_lib.PAIR_TOO_WIDE, _lib.PAIR_TOO_LONG):   # kernel limits the oracle does not have
+                continue
+            if int(o["status"]) != ko:
+                bad = (p, "status", int(o["status"]), ko); break
+            if ko != 0:
+                continue
+            for fld in FIELDS:
+                if int(o[fld]) != int(k[fld]):
+                    bad = (p, fld, int(o[fld]), int(k[fld])); break
+            if bad:
+                break
+            kb = blocks[int(k["blk_off"]):int(k["blk_off"]) + int(k["n_blk"])]
+            ob = oblk[p]
+            if len(kb) != len(ob) or not (np.array_equal(kb["q_pos"], ob["q_pos"]) and np.array_equal(kb["t_pos"], ob["t_pos"])
+                                          and np.array_equal(kb["length"], ob["length"])):
+                bad = (p, "blocks", len(ob), len(kb)); break
+        rounds += 1; pairs_done += n
+        for v, c in zip(*np.unique(pairs["status"], return_counts=True)):
+            hist[int(v)] = hist.get(int(v), 0) + int(c)
+        modes[kw["mode"]] = modes.get(kw["mode"], 0) + n
+        if bad:
+            fails += 1
+            p = bad[0]
+            qo, ql = int(batch["q_off"][p]), int(batch["q_len"][p])
+            to, tl = int(batch["t_off"][p]), int(batch["t_len"][p])
+            bo, nb = int(batch["blk_off"][p]), int(batch["n_blk"][p])
+            rep = {"scoring": kw, "what": [str(x) for x in bad],
+                   "q": bytes(batch["q_arena"][qo:qo + ql]).decode("latin1"),
+                   "t": bytes(batch["t_arena"][to:to + tl]).decode("latin1"),
+                   "blocks": [[int(b["q_pos"]), int(b["t_pos"]), int(b["length"])] for b in batch["blocks"][bo:bo + nb]]}
+            with open(os.path.join(ROOT, "gpurun_out", "fuzz_fail_%d.json" % fails), "w") as f:
+                json.dump(rep, f)
+            print("MISMATCH", bad, kw, flush=True)
+            if fails >= 5:
+                break
+        if rounds % 20 == 0:
+            print("rounds %d pairs %d fails %d unsupported-scoring %d" % (rounds, pairs_done, fails, unsupported), flush=True)
+    print("DONE rounds %d pairs %d fails %d unsupported-scoring %d" % (rounds, pairs_done, fails, unsupported), flush=True)
+    print("status histogram", hist, "pairs per mode", modes, flush=True)
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
