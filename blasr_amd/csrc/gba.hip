@@ -895,7 +895,7 @@ constexpr int TB_RW = 64, TB_TW = 16;
 constexpr int TB_LANES = GBA_TB_LANES;      // pairs per wave: the walk is a dependent chain, more waves hide more of it
 
 template <bool AFF>
-__global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_pair_result *res, uint32_t n_lane)
+__global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_pair_result *res, uint32_t first, uint32_t count)
 {
     __shared__ int32_t sub[25];
     __shared__ uint32_t rwin[TB_RW * TB_LANES];
@@ -903,11 +903,10 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
     if (threadIdx.x < 25) sub[threadIdx.x] = tc_.sub[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x;
-    const uint32_t idx = blockIdx.x * TB_LANES + threadIdx.x;
-    const uint32_t n_ok = n_lane;                 // pairs of the lane-per-pair classes come first in `order`
-    if (blockIdx.x * TB_LANES >= n_ok) return;
-    const uint32_t p = d.order[idx < n_ok ? idx : n_ok - 1];
-    const bool live = idx < n_ok && d.status[p] == GBA_PAIR_OK;   // else: fill found the end cell unreachable
+    const uint32_t idx = blockIdx.x * TB_LANES + threadIdx.x;    // serves order[first .. first + count)
+    if (blockIdx.x * TB_LANES >= count) return;
+    const uint32_t p = d.order[first + (idx < count ? idx : count - 1)];
+    const bool live = idx < count && d.status[p] == GBA_PAIR_OK;   // else: fill found the end cell unreachable
     const uint32_t Q = d.Q[p], T = d.T[p];
     const uint32_t *rec = d.rec + d.rec_off[p];
     const uint32_t *tc4 = (const uint32_t *)(d.tcodes + tc_offset(d, p));   // 4 column codes per dword
@@ -1330,55 +1329,53 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     gba_pair_result *res = out->pairs;
     hipLaunchKernelGGL(k_results_init, dim3(g256), dim3(256), 0, s, d, res);
     if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
-    // One launch per non-empty class, widest class first: the few waves of a wide class run
-    // longest and overlap with the bulk.  The first two launches go to auxiliary streams (the
-    // runtime exposes few hardware queues), the rest to the main stream.
+    // One fill launch per non-empty class, widest class first (its few waves run longest), each
+    // followed on the same stream by the traceback of that class's pairs.  The first two classes
+    // go to auxiliary streams (the runtime exposes few hardware queues) and run beside the bulk on
+    // the main stream, which does all its fills first and then its tracebacks.
     uint32_t launches = 0;
     {
+        const bool aff = sc.mode == GBA_MODE_AFFINE;
+        auto launch_tb = [&](int k, hipStream_t st) {
+            const uint32_t cnt = pl.cls_count[k], first = pl.cls_base[k];
+            if (k == CLS_WIDE && !aff) { hipLaunchKernelGGL(k_traceback_wide, dim3(cnt), dim3(64), 0, st, d, c->tbc, res); return; }
+            const dim3 grid((cnt + TB_LANES - 1) / TB_LANES), block(TB_LANES);
+            if (aff) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, st, d, c->tbc, res, first, cnt);
+            else hipLaunchKernelGGL(k_traceback<false>, grid, block, 0, st, d, c->tbc, res, first, cnt);
+        };
         HIPCHK(c, hipEventRecord(c->ev_fork, s));
         bool used[NAUX] = {};
+        int on_main[NCLS], n_main = 0, nonempty = 0;
+        for (int k = 0; k < NCLS; k++) nonempty += pl.cls_count[k] ? 1 : 0;
+        const uint32_t n_aux = nonempty > 2 ? 2u : nonempty > 0 ? (uint32_t)nonempty - 1u : 0u;   // the narrowest class stays on the main stream
         for (int k = NCLS - 1; k >= 0; k--) {
             const uint32_t cnt = pl.cls_count[k];
             if (!cnt) continue;
             hipStream_t st = s;
-            if (launches < 2) {
+            const bool aux = launches < n_aux;
+            if (aux) {
                 const int a = (int)launches;
                 st = c->aux[a];
                 HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0));
                 used[a] = true;
-            }
-            if (k == CLS_WIDE && sc.mode != GBA_MODE_AFFINE) {
+            } else on_main[n_main++] = k;
+            if (k == CLS_WIDE && !aff) {
                 hipLaunchKernelGGL(k_fill_wide, dim3(cnt), dim3(64), 0, st, d, c->fc);
                 HIPCHK(c, hipGetLastError());
             } else {
                 int rc = launch_fill(c, d, (uint32_t)k, cnt, st);
                 if (rc) return rc;
             }
+            if (aux) launch_tb(k, st);
             launches++;
         }
+        if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
+        for (int x = 0; x < n_main; x++) launch_tb(on_main[x], s);
+        HIPCHK(c, hipGetLastError());
         for (int a = 0; a < NAUX; a++) {
             if (!used[a]) continue;
             HIPCHK(c, hipEventRecord(c->ev_join[a], c->aux[a]));
             HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[a], 0));
-        }
-    }
-    if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    if (pl.n_ok)
-    {
-        const bool aff = sc.mode == GBA_MODE_AFFINE;
-        const uint32_t n_wide = aff ? 0u : pl.cls_count[CLS_WIDE], n_lane = pl.n_ok - n_wide;
-        const dim3 grid((n_lane + TB_LANES - 1) / TB_LANES), block(TB_LANES);
-        // the two tracebacks work on disjoint pairs: the wave-per-pair one runs beside the other
-        if (n_wide) {
-            hipStream_t ws = n_lane ? c->aux[0] : s;
-            if (n_lane) { HIPCHK(c, hipEventRecord(c->ev_fork, s)); HIPCHK(c, hipStreamWaitEvent(ws, c->ev_fork, 0)); }
-            hipLaunchKernelGGL(k_traceback_wide, dim3(n_wide), dim3(64), 0, ws, d, c->tbc, res);
-            if (n_lane) HIPCHK(c, hipEventRecord(c->ev_join[0], ws));
-        }
-        if (n_lane) {
-            if (aff) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, s, d, c->tbc, res, n_lane);
-            else hipLaunchKernelGGL(k_traceback<false>, grid, block, 0, s, d, c->tbc, res, n_lane);
-            if (n_wide) HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[0], 0));
         }
     }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));

@@ -135,8 +135,9 @@ typedef struct {
 
 /* live measurements of the last waited batch (GBA_FLAG_TIMING) */
 typedef struct {
-    float fill_ms;              /* DP-fill kernels, HIP events on the ctx stream */
-    float traceback_ms;
+    float fill_ms;              /* DP-fill launches on the ctx stream (HIP events): the narrowest classes, i.e. the
+                                   bulk of a batch; up to two wider classes run beside them on other streams */
+    float traceback_ms;         /* traceback launches on the ctx stream, same convention */
     float total_ms;             /* first kernel to last kernel of the batch */
     uint32_t fill_launches;
     uint64_t cells;             /* sum of ncells over pairs with status OK */
