@@ -37,6 +37,7 @@ namespace {
 // vectors that are only dword aligned (per-lane positions in dword streams)
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32u1 __attribute__((aligned(1)));   // a dword at any byte address
 
 constexpr uint32_t INFW = 0x40000000u;       // "no path" cell word
 constexpr int32_t UNREACH = 0x20000000;      // unbiased words at or above this are unreachable
@@ -316,7 +317,6 @@ __device__ __forceinline__ uint32_t wave_prev(uint32_t v, uint32_t first)
 
 __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max_band, int kband_k)
 {
-    __shared__ uint32_t mark[64];
     __shared__ uint32_t bwin[(GD_WIN + 2) * 3];
     const uint32_t p = blockIdx.x;
     const int lane = threadIdx.x;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
     bool loaded = false;
     int32_t carry_lo = 0;
     uint32_t carry_e = 0, nw = 0;                // previous row's hi + 1; words produced
-    uint64_t ncells = 0;
+    uint32_t ncells32 = 0;                       // per lane: at most 1024 rows of at most 2047 cells
     uint32_t span = 0, recdw = 0;
     bool wide = false;
     for (uint32_t r0 = 0; r0 <= Q; r0 += 64) {
@@ -350,21 +350,24 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
                     const uint32_t bi = wb + k - 1u;         // wraps for the slot in front of block 0
                     if (bi < nb) { bwin[3 * k] = bl[3 * bi]; bwin[3 * k + 1] = bl[3 * bi + 1]; bwin[3 * k + 2] = bl[3 * bi + 2]; }
                 }
+                __syncthreads();
             }
-            mark[lane] = 0;
-            __syncthreads();
+            // unit u starts on the row after the last row of block u - 1; the starts that fall into
+            // this iteration's rows sit in the first lanes (they increase with u): every row counts
+            // how many of them it has passed
+            uint32_t rs = 0xffffffffu;
             {
-                // unit u starts on the row after the last row of block u - 1
                 const uint32_t u = ub + 1u + lane;
                 if (u < nb) {
                     const uint32_t *pb = bwin + 3 * (u - wb);        // block u - 1
-                    const uint32_t rs = pb[0] + pb[2] - qS + 1u;
-                    if (rs - r0 < 64u) mark[rs - r0] = u;
+                    rs = pb[0] + pb[2] - qS + 1u;
                 }
             }
-            __syncthreads();
-            const uint32_t unit = (uint32_t)max(wave_scan_max((int32_t)mark[lane]), (int32_t)ub);
-            ub = (uint32_t)__builtin_amdgcn_readlane((int32_t)unit, 63);
+            const uint32_t nstart = (uint32_t)__popcll(__ballot(rs - r0 < 64u));
+            uint32_t unit = ub;
+            for (uint32_t k = 0; k < nstart; k++)
+                unit += r >= (uint32_t)__builtin_amdgcn_readlane((int32_t)rs, (int)k) ? 1u : 0u;
+            ub += nstart;
             if (valid && r > 0) {
                 const uint32_t x = r - 1u;
                 const uint32_t *cb = bwin + 3 * (unit - wb + 1u);    // block `unit`
@@ -397,14 +400,17 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
         const uint32_t off = nw + incl - words;
         nw += (uint32_t)__builtin_amdgcn_readlane((int32_t)incl, 63);
         if (valid) {
-            ncells += (uint64_t)(c - lo) + w + 1u;
+            ncells32 += (c - lo) + w + 1u;
             span = max(span, dl + W);
             recdw += 1u + (mode == GBA_MODE_AFFINE ? (W + 3u) >> 2 : (W + 15u) >> 4);
             if (dl > 1023u || W > 1023u) wide = true;
             uint32_t word = (W & ROW_W_MASK) | ((r > 0u ? base_code(qa[r - 1u]) : 4u) << 10) | ((dl & 1023u) << 13);
-            if (nnew > 0u) word |= (uint32_t)tc[cnew] << 23;
-            if (nnew > 1u) word |= (uint32_t)tc[cnew + 1u] << 26;
-            if (nnew > 2u) word |= (uint32_t)tc[cnew + 2u] << 29;
+            if (nnew > 0u) {
+                const uint32_t t4 = *(const u32u1 *)(tc + cnew);           // codes of columns cnew .. cnew + 3 (padding behind the last one)
+                word |= (t4 & 7u) << 23;
+                if (nnew > 1u) word |= ((t4 >> 8) & 7u) << 26;
+                if (nnew > 2u) word |= ((t4 >> 16) & 7u) << 29;
+            }
             if (off < wcap) g[off] = word;
             uint32_t o = off + 1u;
             for (uint32_t j = 3; j < nnew; j += 8, o++) {
@@ -416,6 +422,7 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
         }
     }
     // totals of the pair
+    uint64_t ncells = ncells32;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         ncells += __shfl_xor((unsigned long long)ncells, o, 64);
