@@ -1019,6 +1019,7 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
     if (tc_.affine) score += (int32_t)nopen * tc_.aopen + (int32_t)(nI + nD) * tc_.aext;
     else score += (int32_t)nI * tc_.ins + (int32_t)nD * tc_.del;
     R.n_blk = nb; R.score = score;
+    d.span[p] = nb;
     R.n_match = nM; R.n_mismatch = ndiag - nM; R.n_ins = nI; R.n_del = nD;
 }
 
@@ -1123,6 +1124,7 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
     if (tc_.affine) score += (int32_t)nopen * tc_.aopen + (int32_t)(nI + nD) * tc_.aext;
     else score += (int32_t)nI * tc_.ins + (int32_t)nD * tc_.del;
     R.n_blk = nb; R.score = score;
+    d.span[p] = nb;
     R.n_match = nM; R.n_mismatch = ndiag - nM; R.n_ins = nI; R.n_del = nD;
 }
 
@@ -1135,22 +1137,23 @@ __global__ void k_results_init(Dev d, gba_pair_result *res)
     memset(&r, 0, sizeof(r));
     r.status = d.status[p];
     res[p] = r;
+    d.span[p] = 0;             // from here on: the pair's block count (written by the tracebacks)
 }
 
-// n_blk -> blk_off (single block); pairs whose blocks do not fit the arena get NOSPACE
-__global__ __launch_bounds__(1024) void k_scan1(Dev d, gba_pair_result *res, uint64_t capacity, uint64_t *needed)
+// n_blk -> offsets into the caller's block arena (single block).  The block counts come from
+// d.span (free after k_plan: k_results_init zeroes it, the tracebacks store the counts there), the
+// offsets go to d.word_off (free after the fill kernels).
+__global__ __launch_bounds__(1024) void k_scan1(Dev d, uint64_t *needed)
 {
     __shared__ uint64_t sm[17];
     uint64_t carry = 0;
     // four consecutive pairs per thread
     for (uint32_t b0 = 0; b0 < d.n; b0 += 4 * blockDim.x) {
         uint64_t v[4], lv = 0;
-        bool ok[4];
 #pragma unroll
         for (int x = 0; x < 4; x++) {
             const uint32_t p = b0 + 4 * threadIdx.x + x;
-            ok[x] = p < d.n && d.status[p] == GBA_PAIR_OK;
-            v[x] = ok[x] ? res[p].n_blk : 0;
+            v[x] = p < d.n && d.status[p] == GBA_PAIR_OK ? d.span[p] : 0;
             lv += v[x];
         }
         uint64_t tot;
@@ -1158,17 +1161,7 @@ __global__ __launch_bounds__(1024) void k_scan1(Dev d, gba_pair_result *res, uin
 #pragma unroll
         for (int x = 0; x < 4; x++) {
             const uint32_t p = b0 + 4 * threadIdx.x + x;
-            if (p < d.n) {
-                gba_pair_result &R = res[p];
-                R.status = d.status[p];
-                R.blk_off = e;
-                if (ok[x]) {
-                    R.dp_score = d.dp_score[p];
-                    R.q_pos = d.qS[p]; R.t_pos = d.tS[p];
-                    R.rows = d.Q[p]; R.cols = d.T[p]; R.ncells = d.ncells[p];
-                    if (e + v[x] > capacity) R.status = GBA_PAIR_NOSPACE;
-                }
-            }
+            if (p < d.n) d.word_off[p] = e;
             e += v[x];
         }
         carry += tot;
@@ -1176,13 +1169,29 @@ __global__ __launch_bounds__(1024) void k_scan1(Dev d, gba_pair_result *res, uin
     if (threadIdx.x == 0) *needed = carry;
 }
 
-__global__ __launch_bounds__(256) void k_emit(Dev d, const gba_pair_result *res, gba_block *out)
+// One block per pair: completes the pair's result record and copies its blocks into the caller's
+// arena; pairs whose blocks do not fit get NOSPACE.
+__global__ __launch_bounds__(256) void k_emit(Dev d, gba_pair_result *res, gba_block *out, uint64_t capacity)
 {
     const uint32_t p = blockIdx.x;
-    if (res[p].status != GBA_PAIR_OK) return;
-    const uint32_t nb = res[p].n_blk, cap = d.Q[p] + 1;
-    const gba_block *src = d.blk_scratch + d.row_off[p] + (cap - nb);
-    gba_block *dst = out + res[p].blk_off;
+    const int st = d.status[p];
+    const uint64_t off = d.word_off[p];
+    const uint32_t nb = st == GBA_PAIR_OK ? d.span[p] : 0u;
+    const bool fits = off + nb <= capacity;
+    if (threadIdx.x == 0) {
+        gba_pair_result &R = res[p];
+        R.status = st;
+        R.blk_off = off;
+        if (st == GBA_PAIR_OK) {
+            R.dp_score = d.dp_score[p];
+            R.q_pos = d.qS[p]; R.t_pos = d.tS[p];
+            R.rows = d.Q[p]; R.cols = d.T[p]; R.ncells = d.ncells[p];
+            if (!fits) R.status = GBA_PAIR_NOSPACE;
+        }
+    }
+    if (st != GBA_PAIR_OK || !fits) return;
+    const gba_block *src = d.blk_scratch + d.row_off[p] + (d.Q[p] + 1 - nb);
+    gba_block *dst = out + off;
     for (uint32_t x = threadIdx.x; x < nb; x += blockDim.x) dst[x] = src[x];
 }
 
@@ -1386,8 +1395,8 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
         }
     }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
-    hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, s, d, res, out->blocks_capacity, (uint64_t *)c->b_needed.ptr);
-    hipLaunchKernelGGL(k_emit, dim3(n), dim3(256), 0, s, d, res, out->blocks);
+    hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, s, d, (uint64_t *)c->b_needed.ptr);
+    hipLaunchKernelGGL(k_emit, dim3(n), dim3(256), 0, s, d, res, out->blocks, out->blocks_capacity);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_needed, c->b_needed.ptr, 8, hipMemcpyDeviceToHost, s));
     if (timing) HIPCHK(c, hipEventRecord(c->ev[4], s));
