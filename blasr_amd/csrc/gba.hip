@@ -116,8 +116,8 @@ __device__ __forceinline__ uint32_t base_code(uint8_t c)
 }
 
 __device__ __forceinline__ uint64_t align16(uint64_t x) { return (x + 15) & ~uint64_t(15); }
-// code arrays of a pair start 16-byte aligned and are followed by at least 17 spare bytes
-__device__ __forceinline__ uint64_t tc_offset(const Dev &d, uint32_t p) { return align16(d.col_off[p] + 32ull * p); }
+// code arrays of a pair start 16-byte aligned and are followed by at least 33 spare bytes
+__device__ __forceinline__ uint64_t tc_offset(const Dev &d, uint32_t p) { return align16(d.col_off[p] + 48ull * p); }
 
 // ---------------------------------------------------------------- k_meta
 // DP region of each pair.  Guided modes: from the first block's start to the last block's end
@@ -248,13 +248,31 @@ __global__ __launch_bounds__(256) void k_pack(Dev d)
     // forward: column j is slice byte tS + j - 1; reverse complement: the slice read backwards from
     // its last byte, bases complemented (A<->T, C<->G, N stays)
     const uint8_t *t = d.t_arena + d.t_off[p] + (rc ? (uint64_t)d.t_len[p] - d.tS[p] : (uint64_t)d.tS[p]);
-    for (uint32_t j = threadIdx.x; j <= T + 16; j += blockDim.x) {
-        uint32_t code = 4u;
-        if (j >= 1 && j <= T) {
-            if (rc) { const uint32_t f = base_code(*(t - j)); code = f < 4u ? 3u - f : 4u; }
-            else code = base_code(t[j - 1]);
+    // four columns per thread: one (unaligned) dword in, one aligned dword out
+    for (uint32_t j0 = 4 * threadIdx.x; j0 <= T + 16; j0 += 4 * blockDim.x) {
+        uint32_t in = 0;
+        if (j0 >= 1 && j0 + 3 <= T) {
+            // forward: bytes t[j0-1 .. j0+2]; reverse: bytes t[-j0-3 .. -j0], last one first
+            in = rc ? __builtin_bswap32(*(const u32u1 *)(t - j0 - 3)) : *(const u32u1 *)(t + j0 - 1);
+        } else {
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const uint32_t j = j0 + x;
+                if (j >= 1 && j <= T) in |= (uint32_t)(rc ? *(t - j) : t[j - 1]) << (8 * x);
+            }
         }
-        tc[j] = (uint8_t)(code + 1u);
+        uint32_t outw = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const uint32_t j = j0 + x;
+            uint32_t code = 4u;
+            if (j >= 1 && j <= T) {
+                const uint32_t f = base_code((uint8_t)(in >> (8 * x)));
+                code = rc && f < 4u ? 3u - f : f;
+            }
+            outw |= (code + 1u) << (8 * x);
+        }
+        *(uint32_t *)(tc + j0) = outw;
     }
 }
 
@@ -1327,7 +1345,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     HIPCHK(c, hipStreamSynchronize(s));
     const uint64_t rows = c->h_plan->total_rows, cols = c->h_plan->total_cols;
     { int rc = ensure(c, c->b_guide, (size_t)(c->h_plan->total_words + 16) * 4); if (rc) return rc; }
-    { int rc = ensure(c, c->b_tc, (size_t)(cols + 32ull * n + 64 + 2 * ARENA_SLACK)); if (rc) return rc; }
+    { int rc = ensure(c, c->b_tc, (size_t)(cols + 48ull * n + 64 + 2 * ARENA_SLACK)); if (rc) return rc; }
     { int rc = ensure(c, c->b_blk, (size_t)(rows + 4) * sizeof(gba_block)); if (rc) return rc; }
     d.stream = (uint32_t *)c->b_guide.ptr;
     d.tcodes = (uint8_t *)c->b_tc.ptr + ARENA_SLACK;
