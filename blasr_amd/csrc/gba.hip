@@ -47,9 +47,9 @@ constexpr uint32_t MAX_COLS = 1u << 20;
 // Classes of the lane-per-pair fill kernel: a pair's class is the smallest LDS row buffer
 // (32 << class slots) that holds its widest "shift + width".  Each non-empty class is one launch.
 constexpr int NCLS = 5;                      // lane-per-pair classes of 32, 64, 128, 256 slots, then the wave-per-pair class
-constexpr int CLS_WIDE = NCLS - 1;           // pairs of the linear modes too wide for the lane classes in use: k_fill_wide
+constexpr int CLS_WIDE = NCLS - 1;           // pairs too wide for the lane classes in use: k_fill_wide / k_fill_wide_affine
 constexpr int LANE_CLS_LINEAR = 3;           // linear gaps: lane classes up to 128 slots, anything wider is cheaper wave-per-pair
-constexpr int LANE_CLS_AFFINE = 4;           // affine gaps: lane classes up to 256 slots (two rings), no wave-per-pair kernel
+constexpr int LANE_CLS_AFFINE = 3;           // affine gaps: the same (two rings per wave)
 constexpr int PAD_SLOTS = 3;                 // spare slots behind a ring
 constexpr int SPAN_MARGIN = 4;               // a pair fits a class if its widest shift + width <= slots - SPAN_MARGIN (k_fill touches up to 7 slots past a row end)
 constexpr int CAP_LINEAR = 32, CAP_AFFINE = 40;   // cells per lane per step of k_fill (band 10 rows are 21+ cells, band 16 rows 33+)
@@ -900,6 +900,126 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc)
     }
 }
 
+// ---------------------------------------------------------------- k_fill_wide_affine
+// Wave-per-pair fill for the affine model: lane per column as in k_fill_wide, the rings of the
+// match state M and the insertion-gap state I in LDS.  Along the row two things travel: the linear
+// deletion (M[k-1] + del) and the deletion-gap state D (opened from M[k-1], extended from D[k-1]).
+// With a(j) the best score of column j over the moves that do not come from the left (diagonal,
+// insertion, closing an insertion gap), the score of M[k] is
+//     x(k) = min( a(k), min over j < k of a(j) + f(k - j) ),  f(n) = min( n * P, OE + (n - 1) * E )
+// (P = min(del, open + extend), OE = open + extend, E = extend: n linear steps, or one gap of
+// length n), and the score of D[k] is  y(k) = min over j < k of a(j) + OE + (k - j - 1) * min(P, E).
+// Both are prefix minima of a(j) - j * slope for the two slopes P and E: two wave scans with scalar
+// carries between chunks.  The words of the left neighbour are then rebuilt from x and y, and the
+// arrow, the gap bits and the tie-breaks are decided per cell exactly as in k_fill<true>.
+__global__ __launch_bounds__(64) void k_fill_wide_affine(Dev d, FillConst fc)
+{
+    __shared__ uint32_t ringM[WIDE_RING];
+    __shared__ uint32_t ringI[WIDE_RING];
+    __shared__ uint32_t sbuf[WIDE_SBUF];
+    __shared__ uint32_t tab[LDS_TAB];
+    constexpr uint32_t TAGS = 63u;
+    constexpr int32_t BIG = 0x60000000;
+    const int lane = threadIdx.x;
+    if (lane < 10) tab[lane] = fc.mrow[lane];
+    const uint32_t p = d.order[d.plan->cls_base[CLS_WIDE] + blockIdx.x];
+    const uint32_t Q = d.Q[p];
+    const uint32_t fslot = d.T[p] - d.lo_last[p];
+    const uint32_t *st = d.stream + d.word_off[p];
+    const uint32_t wcap = d.wcap[p];
+    uint32_t *rec = d.rec + d.rec_off[p];
+    const int32_t OE = fc.cDO, E = fc.cDE - 2;          // open + extend, extend, in cell-word units
+    const int32_t DL = fc.del * 64;
+    const int32_t P = min(DL, OE);
+    const bool y_by_e = E <= P;                         // slope of the cheapest way to lengthen a path that ends in the gap state
+    uint32_t spos = 0, sload = 0;
+    uint32_t W = 0, Wp = 0, dsh = 0, roff = 0;
+    __syncthreads();
+    for (uint32_t r = 0; r <= Q; r++) {
+        while (sload - spos < 256u && sload < wcap) {
+            const uint32_t x = sload + lane;
+            const uint32_t v = x < wcap ? st[x] : 0u;
+            sbuf[x & (WIDE_SBUF - 1)] = v;
+            sload += 64;
+        }
+        __syncthreads();
+        const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)sbuf[spos & (WIDE_SBUF - 1)]);
+        Wp = W;
+        W = word & ROW_W_MASK; dsh = (word >> 13) & 1023u;
+        const uint32_t qcode = (word >> 10) & 7u;
+        const uint32_t mlo = tab[qcode * 2], mhi = tab[qcode * 2 + 1];
+        const uint32_t tot = dsh + W;
+        const uint32_t nnew = tot > Wp ? tot - Wp : 0u;
+        for (uint32_t x = lane; x < nnew; x += 64) {
+            uint32_t code;
+            if (x < 3u) code = (word >> (23u + 3u * x)) & 7u;
+            else {
+                const uint32_t e = (x - 3u) >> 3, rr = (x - 3u) & 7u;
+                code = (sbuf[(spos + 1u + e) & (WIDE_SBUF - 1)] >> (3u * rr)) & 7u;
+            }
+            ringM[Wp + x] = INFW | code;
+            ringI[Wp + x] = INFW;
+        }
+        spos += 1u + (nnew > 3u ? (nnew + 4u) >> 3 : 0u);
+        __syncthreads();
+        // row 0: the diagonal candidate of cell (0,0) costs exactly 0
+        uint32_t cdiag = r == 0 ? (uint32_t)fc.diag0 : dsh >= 1u && dsh - 1u < Wp ? ringM[dsh - 1u] : INFW;
+        int32_t carry1 = BIG, carry2 = BIG;             // prefix minima of the columns left of the chunk, as seen from its first column
+        uint32_t xl = INFW, yl = INFW;                  // M and D score of the column left of the chunk
+        const uint32_t nd = (W + 3u) >> 2;
+        for (uint32_t c0 = 0; c0 < W; c0 += 64) {
+            const uint32_t k = c0 + lane;
+            const uint32_t up = ringM[k + dsh], upi = ringI[k + dsh];
+            __syncthreads();                            // every lane has read its slots before any is overwritten
+            const uint32_t diag = (uint32_t)__builtin_amdgcn_update_dpp((int32_t)cdiag, (int32_t)up, 0x138, 0xf, 0xf, false);
+            cdiag = (uint32_t)__builtin_amdgcn_readlane((int32_t)up, 63);
+            const uint32_t tcd = up & 7u;
+            const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);
+            const int32_t m = (int32_t)((sb << 6) + diag);
+            const int32_t u = (int32_t)up + fc.cU;
+            const int32_t io = (int32_t)(up & ~TAGS) + fc.cIO, ie = (int32_t)upi + fc.cIE;
+            const uint32_t ig = (uint32_t)min(io, ie);                 // bit 2: 1 = extend
+            const int32_t ic = (int32_t)ig + (4 << 3);
+            const int32_t av = min(m, min(u, ic));                     // best of the moves that do not come from the left
+            const int32_t a = (int32_t)((uint32_t)av & ~TAGS);
+            const int32_t inc1 = wave_scan_min(a - lane * P, BIG), inc2 = wave_scan_min(a - lane * E, BIG);
+            const int32_t ex1 = __builtin_amdgcn_update_dpp(BIG, inc1, 0x138, 0xf, 0xf, false);
+            const int32_t ex2 = __builtin_amdgcn_update_dpp(BIG, inc2, 0x138, 0xf, 0xf, false);
+            const int32_t s1 = min(ex1, carry1) + lane * P;            // best a(j) + (k - j) * P over j < k
+            const int32_t s2 = min(ex2, carry2) + lane * E;            // best a(j) + (k - j) * E over j < k
+            carry1 = min(__builtin_amdgcn_readlane(inc1, 63), carry1) + 64 * P;
+            carry2 = min(__builtin_amdgcn_readlane(inc2, 63), carry2) + 64 * E;
+            const int32_t x = min(a, min(s1, s2 + OE - E));            // score of M[k]
+            const int32_t y = y_by_e ? s2 + OE - E : s1 + OE - P;      // score of D[k]
+            // the words of the left neighbour, then the cell exactly as the lane-per-pair kernel computes it
+            const uint32_t xp = (uint32_t)__builtin_amdgcn_update_dpp((int32_t)xl, x, 0x138, 0xf, 0xf, false);
+            const uint32_t yp = (uint32_t)__builtin_amdgcn_update_dpp((int32_t)yl, y, 0x138, 0xf, 0xf, false);
+            xl = (uint32_t)__builtin_amdgcn_readlane(x, 63); yl = (uint32_t)__builtin_amdgcn_readlane(y, 63);
+            const int32_t l = (int32_t)xp + fc.cL;
+            const int32_t dop = (int32_t)xp + fc.cDO, de = (int32_t)yp + fc.cDE;
+            const uint32_t dg = (uint32_t)min(dop, de);                // bit 1: 1 = extend
+            const int32_t dc = (int32_t)dg + (3 << 3);
+            const uint32_t best = (uint32_t)min(min(av, l), dc);
+            ringM[k] = (best & ~TAGS) | tcd;
+            ringI[k] = ig & ~TAGS;
+            // record byte: M arrow (bits 3..5) | I bit (bit 2) | D bit (bit 1); 4 columns per dword
+            int32_t ab = (int32_t)(((best & 0x38u) | (ig & 4u) | (dg & 2u)) << (8 * (lane & 3)));
+            ab |= __builtin_amdgcn_update_dpp(0, ab, 0x111, 0xf, 0xf, false);
+            ab |= __builtin_amdgcn_update_dpp(0, ab, 0x112, 0xf, 0xf, false);
+            const uint32_t dwi = (c0 >> 2) + ((uint32_t)lane >> 2);
+            if ((lane & 3) == 3 && dwi < nd) rec[roff + dwi] = (uint32_t)ab;
+        }
+        if (lane == 0) rec[roff + nd] = word & ROW_META_MASK;
+        roff += nd + 1u;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        const int32_t v = (int32_t)(ringM[fslot] & ~TAGS) - (int32_t)Q * (128 << 6);
+        if (v >= UNREACH) d.status[p] = GBA_PAIR_UNREACHABLE;
+        d.dp_score[p] = v >> 6;
+    }
+}
+
 // ---------------------------------------------------------------- k_traceback
 // One lane per pair: from the end cell (Q, T) follow the arrows to (0, 0); merge diagonal runs
 // into blocks (ArrowPathToAlignment), count matches / mismatches / gaps and rescore the path
@@ -1353,7 +1473,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
 
     hipLaunchKernelGGL(k_pack, dim3(n), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_guide, dim3(n), dim3(64), 0, s, d, sc.mode, sc.band, sc.max_band, sc.kband_k);
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, d, sc.mode == GBA_MODE_AFFINE ? LANE_CLS_AFFINE : LANE_CLS_LINEAR, sc.mode == GBA_MODE_AFFINE ? 0 : 1);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, d, sc.mode == GBA_MODE_AFFINE ? LANE_CLS_AFFINE : LANE_CLS_LINEAR, 1);
     HIPCHK(c, hipMemcpyAsync(c->h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const Plan pl = *c->h_plan;
@@ -1393,8 +1513,9 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
                 HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0));
                 used[a] = true;
             } else on_main[n_main++] = k;
-            if (k == CLS_WIDE && !aff) {
-                hipLaunchKernelGGL(k_fill_wide, dim3(cnt), dim3(64), 0, st, d, c->fc);
+            if (k == CLS_WIDE) {
+                if (aff) hipLaunchKernelGGL(k_fill_wide_affine, dim3(cnt), dim3(64), 0, st, d, c->fc);
+                else hipLaunchKernelGGL(k_fill_wide, dim3(cnt), dim3(64), 0, st, d, c->fc);
                 HIPCHK(c, hipGetLastError());
             } else {
                 int rc = launch_fill(c, d, (uint32_t)k, cnt, st);

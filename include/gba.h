@@ -42,7 +42,7 @@ enum {
     GBA_PAIR_UNREACHABLE = 3,      /* the band is disconnected: no path reaches the end cell */
     GBA_PAIR_NOSPACE = 4,          /* blocks of this pair did not fit the caller's arena */
     GBA_PAIR_END_OUT_OF_BAND = 5,  /* k-band: |t_len - q_len| > k */
-    GBA_PAIR_TOO_WIDE = 6,         /* a band row wider than the kernels support (linear, k-band: 1023 cells or a shift of 1023; affine: shift + width > 252) */
+    GBA_PAIR_TOO_WIDE = 6,         /* a band row wider than the kernels support (linear, k-band: 1023 cells or a shift of 1023; affine: the same) */
     GBA_PAIR_TOO_LONG = 7          /* more DP rows or columns than the kernels support (65535 rows, affine 32767; 2^20 columns) */
 };
 

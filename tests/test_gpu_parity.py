@@ -89,6 +89,16 @@ def test_c5_band250(ctx, api, oracle, synth):
     _run(ctx, api, oracle, batch, band=250, tie_break=1, ins=3, dele=6)
 
 
+def test_affine_wide_bands(ctx, api, oracle, synth):
+    """Affine rows wider than the lane-per-pair classes: the wave-per-pair affine kernel."""
+    from blasr_amd import _lib
+    batch = synth.generate(40, read_len=2500, len_jitter=1200, p_ins=0.11, p_del=0.06, p_sub=0.03, seed=5003)
+    for kw in (dict(band=70), dict(band=130, affine_open=4, affine_extend=1), dict(band=250, ins=7, dele=2, tie_break=1),
+               dict(band=90, affine_open=0, affine_extend=0), dict(band=100, dele=20, affine_open=2, affine_extend=9)):
+        pairs, _ = _run(ctx, api, oracle, batch, mode=_lib.MODE_AFFINE, **kw)
+        assert int((pairs["status"] == 0).sum()) == 40
+
+
 def test_wide_mixed_classes(ctx, api, oracle, synth):
     # one batch whose pairs spread over the lane-per-pair classes and the wave-per-pair class
     batch = synth.generate(160, read_len=2500, len_jitter=1500, p_ins=0.12, p_del=0.08, p_sub=0.03, seed=5002)

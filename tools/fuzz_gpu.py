@@ -38,8 +38,6 @@ def random_scoring(rng, _lib):
     kw["band"] = int(rng.choice([0, 1, 2, 3, 5, 10, 16, 25, 40, 70, 120, 250, 300]))
     kw["max_band"] = int(rng.choice([5, 12, 30, 60, 250, 400]))
     if mode == _lib.MODE_AFFINE:
-        kw["band"] = min(kw["band"], 40)
-        kw["max_band"] = min(kw["max_band"], 60)
         kw["affine_open"] = int(rng.integers(0, 30))
         kw["affine_extend"] = int(rng.integers(0, 20))
     if mode == _lib.MODE_KBAND:
