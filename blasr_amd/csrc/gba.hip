@@ -1341,7 +1341,21 @@ struct Buf {
 
 }  // namespace
 
-constexpr int NAUX = 4;
+constexpr int NSLOT = 2;      // a batch can be run as two half batches, staggered, so that one half's guide
+                              // construction and traceback run under the other half's DP fill
+constexpr int NAUXS = 2;      // auxiliary streams per slot (wider classes run beside the bulk class)
+
+// Everything one (half) batch in flight needs of its own.
+struct Slot {
+    Buf b_plan, b_guide, b_tc, b_rec, b_blk;     // device scratch (grow-only)
+    Plan *h_plan = nullptr;                      // pinned
+    hipStream_t s = nullptr, aux[NAUXS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[NAUXS] = {}, ev_done = nullptr;
+    hipEvent_t t_fill0 = nullptr, t_fill1 = nullptr, t_tb1 = nullptr;
+    Plan pl;                                     // host copy of the half batch's plan
+    uint64_t rows = 0;
+    uint32_t launches = 0;
+};
 
 struct gba_ctx {
     int device = 0;
@@ -1353,22 +1367,23 @@ struct gba_ctx {
     gba_scoring sc;
     FillConst fc;
     TbConst tbc;
+    uint32_t split_min = 0xffffffffu; // batches of at least this many pairs are run as two staggered halves (env GBA_SPLIT_MIN).
+                                     // Off by default: on MI355X the halves compete for the same SIMD issue slots and LDS
+                                     // (46.2 ms unsplit, 45.9 ms split with 8 hardware queues, 65 ms with the default 4)
     // device scratch (grow-only)
     Buf b_ref;                       // reference for batches without a target arena (gba_set_reference)
     uint64_t ref_len = 0;
     Buf s_trc;
-    Buf b_pair32[14], b_pair64[5], b_dp, b_plan, b_guide, b_tc, b_rec, b_blk, b_needed;
+    Buf b_pair32[14], b_pair64[5], b_needed;
+    Slot slot[NSLOT];
     // staging for the host-pointer path
     Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res, s_out;
-    Plan *h_plan = nullptr;          // pinned
     uint64_t *h_needed = nullptr;    // pinned
     bool in_flight = false;
     uint32_t flight_n = 0;
     int flight_rc = 0;
     uint64_t flight_needed = 0;
-    hipEvent_t ev[6] = {};
-    hipStream_t aux[4] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[4] = {};
+    hipEvent_t ev[2] = {};           // start and end of a batch
     gba_timing timing = {};
 };
 
@@ -1417,8 +1432,121 @@ int launch_fill(gba_ctx *c, const Dev &d, uint32_t cls, uint32_t count, hipStrea
     return GBA_OK;
 }
 
-// Runs one batch whose inputs and outputs are device pointers.  Synchronises the stream twice
-// (arena sizes, launch grids) and once at the end.
+// The pair range [p0, p0 + cnt) of a batch as a batch of its own: every per-pair array shifted.
+Dev sub_dev(const Dev &g, uint32_t p0, uint32_t cnt, Slot &sl)
+{
+    Dev d = g;
+    d.n = cnt;
+    d.q_off += p0; d.t_off += p0; d.blk_off += p0; d.q_len += p0; d.t_len += p0; d.n_blk += p0;
+    if (d.t_rc) d.t_rc += p0;
+    d.status += p0; d.qS += p0; d.tS += p0; d.Q += p0; d.T += p0; d.rows += p0; d.cols += p0; d.wcap += p0;
+    d.span += p0; d.lo_last += p0; d.cls += p0; d.order += p0; d.recdw += p0;
+    d.row_off += p0; d.col_off += p0; d.word_off += p0; d.rec_off += p0; d.ncells += p0; d.dp_score += p0;
+    d.plan = (Plan *)sl.b_plan.ptr;
+    return d;
+}
+
+// k_meta, arena offsets; the totals travel to the host
+int phase_sizes(gba_ctx *c, Slot &sl, const Dev &d)
+{
+    const gba_scoring &sc = c->sc;
+    hipLaunchKernelGGL(k_meta, dim3((d.n + 255) / 256), dim3(256), 0, sl.s, d, sc.mode, sc.kband_k);
+    hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, sl.s, d);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(sl.h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, sl.s));
+    return GBA_OK;
+}
+
+// after the sizes have arrived: arenas, then target codes, guide stream, classes; the plan travels to the host
+int phase_guide(gba_ctx *c, Slot &sl, Dev &d)
+{
+    const gba_scoring &sc = c->sc;
+    HIPCHK(c, hipStreamSynchronize(sl.s));
+    sl.rows = sl.h_plan->total_rows;
+    const uint64_t cols = sl.h_plan->total_cols;
+    { int rc = ensure(c, sl.b_guide, (size_t)(sl.h_plan->total_words + 16) * 4); if (rc) return rc; }
+    { int rc = ensure(c, sl.b_tc, (size_t)(cols + 48ull * d.n + 64 + 2 * ARENA_SLACK)); if (rc) return rc; }
+    { int rc = ensure(c, sl.b_blk, (size_t)(sl.rows + 4) * sizeof(gba_block)); if (rc) return rc; }
+    d.stream = (uint32_t *)sl.b_guide.ptr;
+    d.tcodes = (uint8_t *)sl.b_tc.ptr + ARENA_SLACK;
+    d.blk_scratch = (gba_block *)sl.b_blk.ptr;
+    hipLaunchKernelGGL(k_pack, dim3(d.n), dim3(256), 0, sl.s, d);
+    hipLaunchKernelGGL(k_guide, dim3(d.n), dim3(64), 0, sl.s, d, sc.mode, sc.band, sc.max_band, sc.kband_k);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, sl.s, d, sc.mode == GBA_MODE_AFFINE ? LANE_CLS_AFFINE : LANE_CLS_LINEAR, 1);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(sl.h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, sl.s));
+    return GBA_OK;
+}
+
+// after the plan has arrived: records arena, then per class the fill launch followed by its
+// traceback.  One launch per non-empty class, widest class first (its few waves run longest);
+// the widest classes go to the slot's auxiliary streams and run beside the bulk on the slot's
+// main stream, which does all its fills first and then its tracebacks.
+int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_aux)
+{
+    const gba_scoring &sc = c->sc;
+    HIPCHK(c, hipStreamSynchronize(sl.s));
+    sl.pl = *sl.h_plan;
+    const Plan &pl = sl.pl;
+    { int rc = ensure(c, sl.b_rec, (size_t)(pl.total_rec_dwords + 16) * 4 + ARENA_SLACK); if (rc) return rc; }
+    d.rec = (uint32_t *)((uint8_t *)sl.b_rec.ptr + ARENA_SLACK);
+    hipStream_t s = sl.s;
+    hipLaunchKernelGGL(k_results_init, dim3((d.n + 255) / 256), dim3(256), 0, s, d, res);
+    HIPCHK(c, hipEventRecord(sl.t_fill0, s));
+    const bool aff = sc.mode == GBA_MODE_AFFINE;
+    auto launch_tb = [&](int k, hipStream_t st) {
+        const uint32_t cnt = pl.cls_count[k], first = pl.cls_base[k];
+        if (k == CLS_WIDE && !aff) { hipLaunchKernelGGL(k_traceback_wide, dim3(cnt), dim3(64), 0, st, d, c->tbc, res); return; }
+        const dim3 grid((cnt + TB_LANES - 1) / TB_LANES), block(TB_LANES);
+        if (aff) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, st, d, c->tbc, res, first, cnt);
+        else hipLaunchKernelGGL(k_traceback<false>, grid, block, 0, st, d, c->tbc, res, first, cnt);
+    };
+    HIPCHK(c, hipEventRecord(sl.ev_fork, s));
+    bool used[NAUXS] = {};
+    int on_main[NCLS], n_main = 0, nonempty = 0;
+    for (int k = 0; k < NCLS; k++) nonempty += pl.cls_count[k] ? 1 : 0;
+    uint32_t n_aux = nonempty > 0 ? (uint32_t)nonempty - 1u : 0u;       // the narrowest class stays on the main stream
+    if (n_aux > max_aux) n_aux = max_aux;
+    sl.launches = 0;
+    for (int k = NCLS - 1; k >= 0; k--) {
+        const uint32_t cnt = pl.cls_count[k];
+        if (!cnt) continue;
+        hipStream_t st = s;
+        const bool aux = sl.launches < n_aux;
+        if (aux) {
+            const int a = (int)sl.launches;
+            st = sl.aux[a];
+            HIPCHK(c, hipStreamWaitEvent(st, sl.ev_fork, 0));
+            used[a] = true;
+        } else on_main[n_main++] = k;
+        if (k == CLS_WIDE) {
+            if (aff) hipLaunchKernelGGL(k_fill_wide_affine, dim3(cnt), dim3(64), 0, st, d, c->fc);
+            else hipLaunchKernelGGL(k_fill_wide, dim3(cnt), dim3(64), 0, st, d, c->fc);
+            HIPCHK(c, hipGetLastError());
+        } else {
+            int rc = launch_fill(c, d, (uint32_t)k, cnt, st);
+            if (rc) return rc;
+        }
+        if (aux) launch_tb(k, st);
+        sl.launches++;
+    }
+    HIPCHK(c, hipEventRecord(sl.t_fill1, s));
+    for (int x = 0; x < n_main; x++) launch_tb(on_main[x], s);
+    HIPCHK(c, hipGetLastError());
+    for (int a = 0; a < NAUXS; a++) {
+        if (!used[a]) continue;
+        HIPCHK(c, hipEventRecord(sl.ev_join[a], sl.aux[a]));
+        HIPCHK(c, hipStreamWaitEvent(s, sl.ev_join[a], 0));
+    }
+    HIPCHK(c, hipEventRecord(sl.t_tb1, s));
+    HIPCHK(c, hipEventRecord(sl.ev_done, s));
+    return GBA_OK;
+}
+
+// Runs one batch whose inputs and outputs are device pointers.  With GBA_SPLIT_MIN set, a batch of
+// at least that many pairs is run as two half batches: the second half's target packing and guide construction are enqueued once the first
+// half's fills are under way, and the first half's traceback runs under the second half's fill.
+// The host waits twice per half (arena sizes, launch grids) and once at the end.
 int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
 {
     const uint32_t n = b->n_pairs;
@@ -1427,127 +1555,77 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     HIPCHK(c, hipSetDevice(c->device));
     for (int i = 0; i < 14; i++) { int rc = ensure(c, c->b_pair32[i], (size_t)n * 4); if (rc) return rc; }
     for (int i = 0; i < 5; i++) { int rc = ensure(c, c->b_pair64[i], (size_t)n * 8); if (rc) return rc; }
-    { int rc = ensure(c, c->b_plan, sizeof(Plan)); if (rc) return rc; }
     { int rc = ensure(c, c->b_needed, 8); if (rc) return rc; }
-    Dev d;
-    memset(&d, 0, sizeof(d));
-    d.n = n;
-    d.q_arena = b->q_arena; d.t_arena = b->t_arena; d.blocks = b->blocks;
-    d.t_rc = b->t_rc;
-    if (!d.t_arena) {            // targets are windows of the ctx reference
+    for (auto &sl : c->slot) { int rc = ensure(c, sl.b_plan, sizeof(Plan)); if (rc) return rc; }
+    Dev g;
+    memset(&g, 0, sizeof(g));
+    g.n = n;
+    g.q_arena = b->q_arena; g.t_arena = b->t_arena; g.blocks = b->blocks;
+    g.t_rc = b->t_rc;
+    if (!g.t_arena) {            // targets are windows of the ctx reference
         if (!c->b_ref.ptr) return GBA_E_STATE;
-        d.t_arena = (const uint8_t *)c->b_ref.ptr; d.t_arena_bytes = c->ref_len;
+        g.t_arena = (const uint8_t *)c->b_ref.ptr; g.t_arena_bytes = c->ref_len;
     }
-    d.q_off = b->q_off; d.t_off = b->t_off; d.blk_off = b->blk_off;
-    d.q_len = b->q_len; d.t_len = b->t_len; d.n_blk = b->n_blk;
-    d.status = (int32_t *)c->b_pair32[0].ptr;
-    d.qS = (uint32_t *)c->b_pair32[1].ptr; d.tS = (uint32_t *)c->b_pair32[2].ptr;
-    d.Q = (uint32_t *)c->b_pair32[3].ptr; d.T = (uint32_t *)c->b_pair32[4].ptr;
-    d.rows = (uint32_t *)c->b_pair32[5].ptr; d.cols = (uint32_t *)c->b_pair32[6].ptr;
-    d.span = (uint32_t *)c->b_pair32[7].ptr; d.lo_last = (uint32_t *)c->b_pair32[8].ptr;
-    d.cls = (uint32_t *)c->b_pair32[9].ptr; d.order = (uint32_t *)c->b_pair32[10].ptr;
-    d.dp_score = (int32_t *)c->b_pair32[11].ptr;
-    d.wcap = (uint32_t *)c->b_pair32[12].ptr;
-    d.recdw = (uint32_t *)c->b_pair32[13].ptr;
-    d.row_off = (uint64_t *)c->b_pair64[0].ptr; d.col_off = (uint64_t *)c->b_pair64[1].ptr;
-    d.rec_off = (uint64_t *)c->b_pair64[2].ptr; d.ncells = (uint64_t *)c->b_pair64[3].ptr;
-    d.word_off = (uint64_t *)c->b_pair64[4].ptr;
-    d.plan = (Plan *)c->b_plan.ptr;
-    const gba_scoring &sc = c->sc;
+    g.q_off = b->q_off; g.t_off = b->t_off; g.blk_off = b->blk_off;
+    g.q_len = b->q_len; g.t_len = b->t_len; g.n_blk = b->n_blk;
+    g.status = (int32_t *)c->b_pair32[0].ptr;
+    g.qS = (uint32_t *)c->b_pair32[1].ptr; g.tS = (uint32_t *)c->b_pair32[2].ptr;
+    g.Q = (uint32_t *)c->b_pair32[3].ptr; g.T = (uint32_t *)c->b_pair32[4].ptr;
+    g.rows = (uint32_t *)c->b_pair32[5].ptr; g.cols = (uint32_t *)c->b_pair32[6].ptr;
+    g.span = (uint32_t *)c->b_pair32[7].ptr; g.lo_last = (uint32_t *)c->b_pair32[8].ptr;
+    g.cls = (uint32_t *)c->b_pair32[9].ptr; g.order = (uint32_t *)c->b_pair32[10].ptr;
+    g.dp_score = (int32_t *)c->b_pair32[11].ptr;
+    g.wcap = (uint32_t *)c->b_pair32[12].ptr;
+    g.recdw = (uint32_t *)c->b_pair32[13].ptr;
+    g.row_off = (uint64_t *)c->b_pair64[0].ptr; g.col_off = (uint64_t *)c->b_pair64[1].ptr;
+    g.rec_off = (uint64_t *)c->b_pair64[2].ptr; g.ncells = (uint64_t *)c->b_pair64[3].ptr;
+    g.word_off = (uint64_t *)c->b_pair64[4].ptr;
     const bool timing = (c->flags & GBA_FLAG_TIMING) != 0;
-    hipStream_t s = c->stream;
-    const uint32_t g256 = (n + 255) / 256;
+    uint32_t p0[NSLOT + 1] = {0, n, n};
+    if (n >= c->split_min) p0[1] = (n / 2 + 63) & ~63u;   // whole waves in the first half
+    const int ns = p0[1] < n ? NSLOT : 1;
+    Dev d[NSLOT];
+    for (int h = 0; h < ns; h++) d[h] = sub_dev(g, p0[h], p0[h + 1] - p0[h], c->slot[h]);
+    gba_pair_result *res = out->pairs;
+    hipStream_t s = c->slot[0].s;
 
     if (timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    hipLaunchKernelGGL(k_meta, dim3(g256), dim3(256), 0, s, d, sc.mode, sc.kband_k);
-    hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, s, d);
-    HIPCHK(c, hipMemcpyAsync(c->h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    const uint64_t rows = c->h_plan->total_rows, cols = c->h_plan->total_cols;
-    { int rc = ensure(c, c->b_guide, (size_t)(c->h_plan->total_words + 16) * 4); if (rc) return rc; }
-    { int rc = ensure(c, c->b_tc, (size_t)(cols + 48ull * n + 64 + 2 * ARENA_SLACK)); if (rc) return rc; }
-    { int rc = ensure(c, c->b_blk, (size_t)(rows + 4) * sizeof(gba_block)); if (rc) return rc; }
-    d.stream = (uint32_t *)c->b_guide.ptr;
-    d.tcodes = (uint8_t *)c->b_tc.ptr + ARENA_SLACK;
-    d.blk_scratch = (gba_block *)c->b_blk.ptr;
-
-    hipLaunchKernelGGL(k_pack, dim3(n), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(k_guide, dim3(n), dim3(64), 0, s, d, sc.mode, sc.band, sc.max_band, sc.kband_k);
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, d, sc.mode == GBA_MODE_AFFINE ? LANE_CLS_AFFINE : LANE_CLS_LINEAR, 1);
-    HIPCHK(c, hipMemcpyAsync(c->h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    const Plan pl = *c->h_plan;
-    { int rc = ensure(c, c->b_rec, (size_t)(pl.total_rec_dwords + 16) * 4 + ARENA_SLACK); if (rc) return rc; }
-    d.rec = (uint32_t *)((uint8_t *)c->b_rec.ptr + ARENA_SLACK);
-
-    gba_pair_result *res = out->pairs;
-    hipLaunchKernelGGL(k_results_init, dim3(g256), dim3(256), 0, s, d, res);
-    if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
-    // One fill launch per non-empty class, widest class first (its few waves run longest), each
-    // followed on the same stream by the traceback of that class's pairs.  The first two classes
-    // go to auxiliary streams (the runtime exposes few hardware queues) and run beside the bulk on
-    // the main stream, which does all its fills first and then its tracebacks.
-    uint32_t launches = 0;
-    {
-        const bool aff = sc.mode == GBA_MODE_AFFINE;
-        auto launch_tb = [&](int k, hipStream_t st) {
-            const uint32_t cnt = pl.cls_count[k], first = pl.cls_base[k];
-            if (k == CLS_WIDE && !aff) { hipLaunchKernelGGL(k_traceback_wide, dim3(cnt), dim3(64), 0, st, d, c->tbc, res); return; }
-            const dim3 grid((cnt + TB_LANES - 1) / TB_LANES), block(TB_LANES);
-            if (aff) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, st, d, c->tbc, res, first, cnt);
-            else hipLaunchKernelGGL(k_traceback<false>, grid, block, 0, st, d, c->tbc, res, first, cnt);
-        };
-        HIPCHK(c, hipEventRecord(c->ev_fork, s));
-        bool used[NAUX] = {};
-        int on_main[NCLS], n_main = 0, nonempty = 0;
-        for (int k = 0; k < NCLS; k++) nonempty += pl.cls_count[k] ? 1 : 0;
-        const uint32_t n_aux = nonempty > 2 ? 2u : nonempty > 0 ? (uint32_t)nonempty - 1u : 0u;   // the narrowest class stays on the main stream
-        for (int k = NCLS - 1; k >= 0; k--) {
-            const uint32_t cnt = pl.cls_count[k];
-            if (!cnt) continue;
-            hipStream_t st = s;
-            const bool aux = launches < n_aux;
-            if (aux) {
-                const int a = (int)launches;
-                st = c->aux[a];
-                HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0));
-                used[a] = true;
-            } else on_main[n_main++] = k;
-            if (k == CLS_WIDE) {
-                if (aff) hipLaunchKernelGGL(k_fill_wide_affine, dim3(cnt), dim3(64), 0, st, d, c->fc);
-                else hipLaunchKernelGGL(k_fill_wide, dim3(cnt), dim3(64), 0, st, d, c->fc);
-                HIPCHK(c, hipGetLastError());
-            } else {
-                int rc = launch_fill(c, d, (uint32_t)k, cnt, st);
-                if (rc) return rc;
-            }
-            if (aux) launch_tb(k, st);
-            launches++;
-        }
-        if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
-        for (int x = 0; x < n_main; x++) launch_tb(on_main[x], s);
-        HIPCHK(c, hipGetLastError());
-        for (int a = 0; a < NAUX; a++) {
-            if (!used[a]) continue;
-            HIPCHK(c, hipEventRecord(c->ev_join[a], c->aux[a]));
-            HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[a], 0));
-        }
+    if (ns == 2) {                                     // the second slot's stream starts after the batch's inputs are ready
+        HIPCHK(c, hipEventRecord(c->slot[0].ev_fork, s));
+        HIPCHK(c, hipStreamWaitEvent(c->slot[1].s, c->slot[0].ev_fork, 0));
     }
-    if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
-    hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, s, d, (uint64_t *)c->b_needed.ptr);
-    hipLaunchKernelGGL(k_emit, dim3(n), dim3(256), 0, s, d, res, out->blocks, out->blocks_capacity);
+    for (int h = 0; h < ns; h++) { int rc = phase_sizes(c, c->slot[h], d[h]); if (rc) return rc; }
+    for (int h = 0; h < ns; h++) {
+        int rc = phase_guide(c, c->slot[h], d[h]); if (rc) return rc;
+        rc = phase_fill(c, c->slot[h], d[h], res + p0[h], (uint32_t)NAUXS); if (rc) return rc;
+    }
+    if (ns == 2) HIPCHK(c, hipStreamWaitEvent(s, c->slot[1].ev_done, 0));
+    hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, s, g, (uint64_t *)c->b_needed.ptr);
+    for (int h = 0; h < ns; h++)
+        hipLaunchKernelGGL(k_emit, dim3(d[h].n), dim3(256), 0, s, d[h], res + p0[h], out->blocks, out->blocks_capacity);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_needed, c->b_needed.ptr, 8, hipMemcpyDeviceToHost, s));
-    if (timing) HIPCHK(c, hipEventRecord(c->ev[4], s));
+    if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     HIPCHK(c, hipStreamSynchronize(s));
     out->blocks_needed = *c->h_needed;
     if (timing) {
+        // fill: from the first bulk fill's start to the last bulk fill's end (the halves overlap);
+        // traceback: from there to the end of the last traceback
         gba_timing &t = c->timing;
-        HIPCHK(c, hipEventElapsedTime(&t.fill_ms, c->ev[1], c->ev[2]));
-        HIPCHK(c, hipEventElapsedTime(&t.traceback_ms, c->ev[2], c->ev[3]));
-        HIPCHK(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[4]));
-        t.fill_launches = launches;
-        t.cells = pl.total_cells; t.rows = rows; t.record_bytes = pl.total_rec_dwords * 4;
+        float f0 = 1e30f, f1 = 0, tb1 = 0;
+        t.fill_launches = 0; t.cells = 0; t.rows = 0; t.record_bytes = 0;
+        for (int h = 0; h < ns; h++) {
+            Slot &sl = c->slot[h];
+            float a, e, x;
+            HIPCHK(c, hipEventElapsedTime(&a, c->ev[0], sl.t_fill0));
+            HIPCHK(c, hipEventElapsedTime(&e, c->ev[0], sl.t_fill1));
+            HIPCHK(c, hipEventElapsedTime(&x, c->ev[0], sl.t_tb1));
+            f0 = a < f0 ? a : f0; f1 = e > f1 ? e : f1; tb1 = x > tb1 ? x : tb1;
+            t.fill_launches += sl.launches; t.cells += sl.pl.total_cells; t.rows += sl.rows;
+            t.record_bytes += sl.pl.total_rec_dwords * 4;
+        }
+        t.fill_ms = f1 - f0; t.traceback_ms = tb1 > f1 ? tb1 - f1 : 0;
+        HIPCHK(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[1]));
     }
     return out->blocks_needed > out->blocks_capacity ? GBA_E_NOSPACE : GBA_OK;
 }
@@ -1593,14 +1671,21 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
         if (hipSetDevice(c->device) != hipSuccess) { rc = GBA_E_HIP; break; }
         if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
         else { if (hipStreamCreate(&c->stream) != hipSuccess) { rc = GBA_E_HIP; break; } c->own_stream = true; }
-        if (hipHostMalloc((void **)&c->h_plan, sizeof(Plan)) != hipSuccess) { rc = GBA_E_NOMEM; break; }
         if (hipHostMalloc((void **)&c->h_needed, 8) != hipSuccess) { rc = GBA_E_NOMEM; break; }
         for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rc = GBA_E_HIP; break; }
         if (rc) break;
-        if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { rc = GBA_E_HIP; break; }
-        for (int a = 0; a < NAUX; a++) {
-            if (hipStreamCreateWithFlags(&c->aux[a], hipStreamNonBlocking) != hipSuccess) { rc = GBA_E_HIP; break; }
-            if (hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming) != hipSuccess) { rc = GBA_E_HIP; break; }
+        if (const char *e = getenv("GBA_SPLIT_MIN")) c->split_min = (uint32_t)strtoul(e, nullptr, 10);
+        for (int h = 0; h < NSLOT && !rc; h++) {
+            Slot &sl = c->slot[h];
+            if (h == 0) sl.s = c->stream;
+            else if (hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking) != hipSuccess) { rc = GBA_E_HIP; break; }
+            if (hipHostMalloc((void **)&sl.h_plan, sizeof(Plan)) != hipSuccess) { rc = GBA_E_NOMEM; break; }
+            hipEvent_t *plain[] = {&sl.ev_fork, &sl.ev_done, &sl.ev_join[0], &sl.ev_join[1]};
+            for (hipEvent_t *e : plain) if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) rc = GBA_E_HIP;
+            hipEvent_t *timed[] = {&sl.t_fill0, &sl.t_fill1, &sl.t_tb1};
+            for (hipEvent_t *e : timed) if (hipEventCreate(e) != hipSuccess) rc = GBA_E_HIP;
+            for (int a = 0; a < NAUXS; a++)
+                if (hipStreamCreateWithFlags(&sl.aux[a], hipStreamNonBlocking) != hipSuccess) rc = GBA_E_HIP;
         }
     } while (0);
     if (rc) { gba_destroy(c); return rc; }
@@ -1615,17 +1700,21 @@ void gba_destroy(gba_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &b : c->b_pair32) release(b);
     for (auto &b : c->b_pair64) release(b);
-    Buf *bs[] = {&c->b_ref, &c->s_trc, &c->b_dp, &c->b_plan, &c->b_guide, &c->b_tc, &c->b_rec, &c->b_blk, &c->b_needed,
+    Buf *bs[] = {&c->b_ref, &c->s_trc, &c->b_needed,
                  &c->s_q, &c->s_t, &c->s_blk, &c->s_qoff, &c->s_toff, &c->s_boff, &c->s_qlen, &c->s_tlen,
                  &c->s_nblk, &c->s_res, &c->s_out};
     for (Buf *b : bs) release(*b);
-    if (c->h_plan) (void)hipHostFree(c->h_plan);
     if (c->h_needed) (void)hipHostFree(c->h_needed);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    for (int a = 0; a < NAUX; a++) {
-        if (c->ev_join[a]) (void)hipEventDestroy(c->ev_join[a]);
-        if (c->aux[a]) { (void)hipStreamSynchronize(c->aux[a]); (void)hipStreamDestroy(c->aux[a]); }
+    for (int h = 0; h < NSLOT; h++) {
+        Slot &sl = c->slot[h];
+        for (int a = 0; a < NAUXS; a++) if (sl.aux[a]) { (void)hipStreamSynchronize(sl.aux[a]); (void)hipStreamDestroy(sl.aux[a]); }
+        if (h > 0 && sl.s) { (void)hipStreamSynchronize(sl.s); (void)hipStreamDestroy(sl.s); }
+        Buf *sb[] = {&sl.b_plan, &sl.b_guide, &sl.b_tc, &sl.b_rec, &sl.b_blk};
+        for (Buf *b : sb) release(*b);
+        if (sl.h_plan) (void)hipHostFree(sl.h_plan);
+        hipEvent_t evs[] = {sl.ev_fork, sl.ev_done, sl.ev_join[0], sl.ev_join[1], sl.t_fill0, sl.t_fill1, sl.t_tb1};
+        for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

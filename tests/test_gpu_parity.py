@@ -342,3 +342,15 @@ def test_reference_windows_and_reverse_complement(ctx, api, oracle, synth):
     ctx.set_reference(None)
     with pytest.raises(Exception):
         ctx.refine_host(wb)          # no reference, no arena: call out of sequence
+
+
+def test_split_batches(api, oracle, synth, monkeypatch):
+    """GBA_SPLIT_MIN: a batch run as two staggered half batches gives the same results."""
+    monkeypatch.setenv("GBA_SPLIT_MIN", "64")
+    c2 = api.Context(0)
+    try:
+        batch = synth.generate(333, read_len=1200, len_jitter=900, p_ins=0.1, p_del=0.07, seed=88, decoy_every=7)
+        for kw in (dict(), dict(band=60), dict(mode=1, band=16)):
+            _run(c2, api, oracle, batch, **kw)
+    finally:
+        c2.close()
