@@ -1165,13 +1165,15 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
 // Traceback of the wave-per-pair class: the rows of such pairs have records of up to 65 dwords, so
 // a lane-private window would hold two or three rows.  Here a WAVE serves one pair: all lanes
 // load the next WT_WIN record dwords (and WT_TC target codes) into LDS with coalesced 16-byte
-// loads, then lane 0 walks the rows that window covers.  Same records, moves and statistics as
-// k_traceback<false>.
+// loads, then the wave walks the rows that window covers.  Same records, moves and statistics as
+// k_traceback.
 constexpr int WT_WIN = 4096;      // record dwords per refill
 constexpr int WT_TC = 2048;       // target codes (bytes) per refill
 
+template <bool AFF>
 __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_pair_result *res)
 {
+    constexpr uint32_t CSHIFT = AFF ? 2u : 4u, CMASK = AFF ? 3u : 15u, BITS = AFF ? 8u : 2u;
     __shared__ int32_t sub[25];
     __shared__ __attribute__((aligned(16))) uint32_t win[WT_WIN];
     __shared__ uint32_t tcw[WT_TC / 4];
@@ -1190,7 +1192,8 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
     uint32_t i = Q, j = T, lo = uni(d.lo_last[p]), nb = 0, run = 0;
     uint32_t nM = 0, ndiag = 0, nopen = 0, prev_op = 0;
     int32_t score = 0;
-    uint32_t budget = Q + T + 2u;
+    uint32_t budget = (Q + T + 2u) * (AFF ? 3u : 1u);   // affine paths spend an extra step on every gap-state change
+    uint32_t state = 0;                                 // affine: 0 match state, 1 insertion gap, 2 deletion gap
     bool ok = true, done = false;
     int32_t pend_v = 0;
     int32_t ptr = (int32_t)uni(d.recdw[p]) - 1;         // meta dword of the current row
@@ -1213,7 +1216,7 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
         }
         __syncthreads();
         uint32_t gw = uni(win[ptr - rb]);
-        uint32_t W = gw & ROW_W_MASK, n = (W + 15u) >> 4;
+        uint32_t W = gw & ROW_W_MASK, n = (W + CMASK) >> CSHIFT;
         for (;;) {
             if ((i | j) == 0u) { done = true; break; }
             if (ptr - (int32_t)n - 1 < rb || (int32_t)j - 1 < jb) break;          // next refill
@@ -1222,12 +1225,25 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
             const int32_t up = ptr - (int32_t)n - 1;                 // meta dword of row i - 1
             // one LDS round trip for the arrow dword, the meta dword of the row above and the target
             // code of column j (the last two are only used by some moves)
-            const uint32_t aw_v = win[up + 1 + (int32_t)(k >> 4) - rb], gup_v = win[up - rb];
+            const uint32_t aw_v = win[up + 1 + (int32_t)(k >> CSHIFT) - rb], gup_v = win[up - rb];
             const uint32_t tb_v = tcw8[(int32_t)j - jb];
             const uint32_t aw = uni(aw_v), gup = uni(gup_v), tbase = uni(tb_v) - 1u;
             score += (int32_t)uni((uint32_t)pend_v); pend_v = 0;
-            const uint32_t a = (aw >> ((k & 15u) * 2u)) & 3u;
-            const uint32_t mv = a == 0u ? 0u : a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : 4u;
+            const uint32_t cell = aw >> ((k & CMASK) * BITS);
+            // move: 0 diagonal, 1 up (insertion), 2 left (deletion), 3 none (state change only), 4 error
+            uint32_t mv;
+            if constexpr (!AFF) {
+                const uint32_t a = cell & 3u;
+                mv = a == 0u ? 0u : a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : 4u;
+            } else {
+                const uint32_t a = (cell >> 3) & 7u;
+                const uint32_t m0 = a == 0u ? 0u : a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : a <= 4u ? 3u : 4u;
+                const uint32_t s0 = a == 3u ? 2u : a == 4u ? 1u : 0u;
+                const uint32_t st = state;
+                mv = st == 0u ? m0 : st;
+                state = st == 0u ? s0 : st == 1u ? ((cell & 4u) ? 1u : 0u) : ((cell & 2u) ? 2u : 0u);
+                if (mv == 3u) continue;
+            }
             if (mv == 4u || (i == 0u && mv != 2u) || (j == 0u && mv != 1u)) { ok = false; done = true; break; }
             if (mv == 0u) {
                 const uint32_t qb = (gw >> 10) & 7u;
@@ -1249,7 +1265,7 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
                 lo -= (gw >> 13) & 1023u;
                 ptr = up;
                 gw = gup;
-                W = gw & ROW_W_MASK; n = (W + 15u) >> 4;
+                W = gw & ROW_W_MASK; n = (W + CMASK) >> CSHIFT;
             }
         }
     }
@@ -1496,7 +1512,11 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
     const bool aff = sc.mode == GBA_MODE_AFFINE;
     auto launch_tb = [&](int k, hipStream_t st) {
         const uint32_t cnt = pl.cls_count[k], first = pl.cls_base[k];
-        if (k == CLS_WIDE && !aff) { hipLaunchKernelGGL(k_traceback_wide, dim3(cnt), dim3(64), 0, st, d, c->tbc, res); return; }
+        if (k == CLS_WIDE) {
+            if (aff) hipLaunchKernelGGL(k_traceback_wide<true>, dim3(cnt), dim3(64), 0, st, d, c->tbc, res);
+            else hipLaunchKernelGGL(k_traceback_wide<false>, dim3(cnt), dim3(64), 0, st, d, c->tbc, res);
+            return;
+        }
         const dim3 grid((cnt + TB_LANES - 1) / TB_LANES), block(TB_LANES);
         if (aff) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, st, d, c->tbc, res, first, cnt);
         else hipLaunchKernelGGL(k_traceback<false>, grid, block, 0, st, d, c->tbc, res, first, cnt);
