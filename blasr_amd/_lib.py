@@ -24,11 +24,19 @@ PAIR_RESULT_DT = np.dtype([
     ("status", "<i4"), ("dp_score", "<i4"), ("score", "<i4"),
     ("q_pos", "<u4"), ("t_pos", "<u4"), ("n_blk", "<u4"), ("blk_off", "<u8"),
     ("n_match", "<u4"), ("n_mismatch", "<u4"), ("n_ins", "<u4"), ("n_del", "<u4"),
-    ("rows", "<u4"), ("cols", "<u4"), ("ncells", "<u8")], align=True)
+    ("rows", "<u4"), ("cols", "<u4"), ("ncells", "<u8"), ("extra_score", "<i4", (2,))], align=True)
 
 
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("flags", C.c_uint32), ("stream", C.c_void_p)]
+
+
+class Rescorer(C.Structure):
+    _fields_ = [("sub", (C.c_int32 * 5) * 5), ("ins", C.c_int32), ("dele", C.c_int32),
+                ("affine_open", C.c_int32), ("affine_extend", C.c_int32), ("affine", C.c_int32)]
+
+
+MAX_EXTRA = 2
 
 
 class Scoring(C.Structure):
@@ -41,6 +49,7 @@ class Scoring(C.Structure):
         ("band", C.c_int32), ("max_band", C.c_int32),
         ("mode", C.c_int32), ("tie_break", C.c_int32),
         ("kband_k", C.c_int32), ("stats_affine", C.c_int32),
+        ("n_extra", C.c_int32), ("extra", Rescorer * MAX_EXTRA),
     ]
 
 

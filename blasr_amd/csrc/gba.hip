@@ -106,7 +106,17 @@ struct TbConst {
     int32_t ins, del, aopen, aext, affine;
     uint32_t codeU, codeL;
     int32_t mode;
+    int32_t n_extra;                       // further rescoring scorers
+    int32_t xsub[GBA_MAX_EXTRA][25];
+    int32_t xins[GBA_MAX_EXTRA], xdel[GBA_MAX_EXTRA], xaopen[GBA_MAX_EXTRA], xaext[GBA_MAX_EXTRA], xaffine[GBA_MAX_EXTRA];
 };
+
+// gap part of a rescoring: nI / nD gap bases in nopen runs
+__device__ __forceinline__ int32_t gap_score(int32_t affine, int32_t ins, int32_t del, int32_t aopen, int32_t aext,
+                                             uint32_t nI, uint32_t nD, uint32_t nopen)
+{
+    return affine ? (int32_t)nopen * aopen + (int32_t)(nI + nD) * aext : (int32_t)nI * ins + (int32_t)nD * del;
+}
 
 __device__ __forceinline__ uint32_t base_code(uint8_t c)
 {
@@ -1042,11 +1052,15 @@ constexpr int TB_LANES = GBA_TB_LANES;      // pairs per wave: the walk is a dep
 template <bool AFF>
 __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_pair_result *res, uint32_t first, uint32_t count)
 {
-    __shared__ int32_t sub[25];
+    __shared__ int32_t sub[25 * (1 + GBA_MAX_EXTRA)];     // the stats scorer's matrix, then the extra scorers'
     __shared__ uint32_t rwin[TB_RW * TB_LANES];
     __shared__ uint32_t twin[TB_TW * TB_LANES];
-    if (threadIdx.x < 25) sub[threadIdx.x] = tc_.sub[threadIdx.x];
+    if (threadIdx.x < 25) {
+        sub[threadIdx.x] = tc_.sub[threadIdx.x];
+        for (int x = 0; x < GBA_MAX_EXTRA; x++) sub[25 * (x + 1) + threadIdx.x] = tc_.xsub[x][threadIdx.x];
+    }
     __syncthreads();
+    const int nx = tc_.n_extra;
     const int lane = threadIdx.x;
     const uint32_t idx = blockIdx.x * TB_LANES + threadIdx.x;    // serves order[first .. first + count)
     if (blockIdx.x * TB_LANES >= count) return;
@@ -1063,6 +1077,7 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
     int32_t score = 0;
     uint32_t prev_op = 0;
     int32_t pend = 0;                             // substitution cost of the last diagonal move, added one step later
+    int32_t xs0 = 0, xs1 = 0;                     // substitution sums of the extra scorers
     // affine paths spend an extra step on every gap-state change
     uint32_t budget = (Q + T + 2u) * (AFF ? 3u : 1u);
     bool ok = true;
@@ -1132,8 +1147,11 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
             ok = !bad;
             const uint32_t qb = (gw >> 10) & 7u;
             nM += dmove && qb == tbase ? 1u : 0u;
-            pend = sub[qb * 5 + min(tbase, 4u)];                          // only kept for a diagonal move
+            const uint32_t si = qb * 5 + min(tbase, 4u);
+            pend = sub[si];                                               // only kept for a diagonal move
             pend = dmove ? pend : 0;
+            if (nx > 0) { const int32_t v = sub[25 + si]; xs0 += dmove ? v : 0; }
+            if (nx > 1) { const int32_t v = sub[50 + si]; xs1 += dmove ? v : 0; }
             ndiag += dmove ? 1u : 0u;
             if (gmove && run != 0u) { outp -= 3; outp[0] = i; outp[1] = j; outp[2] = run; nb++; }
             run = dmove ? run + 1u : gmove ? 0u : run;
@@ -1154,11 +1172,12 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
     if (!ok) { d.status[p] = GBA_PAIR_UNREACHABLE; return; }
     // every row is consumed by a diagonal or an up move, every column by a diagonal or a left move
     const uint32_t nI = Q - ndiag, nD = T - ndiag;
-    if (tc_.affine) score += (int32_t)nopen * tc_.aopen + (int32_t)(nI + nD) * tc_.aext;
-    else score += (int32_t)nI * tc_.ins + (int32_t)nD * tc_.del;
+    score += gap_score(tc_.affine, tc_.ins, tc_.del, tc_.aopen, tc_.aext, nI, nD, nopen);
     R.n_blk = nb; R.score = score;
     d.span[p] = nb;
     R.n_match = nM; R.n_mismatch = ndiag - nM; R.n_ins = nI; R.n_del = nD;
+    if (nx > 0) R.extra_score[0] = xs0 + gap_score(tc_.xaffine[0], tc_.xins[0], tc_.xdel[0], tc_.xaopen[0], tc_.xaext[0], nI, nD, nopen);
+    if (nx > 1) R.extra_score[1] = xs1 + gap_score(tc_.xaffine[1], tc_.xins[1], tc_.xdel[1], tc_.xaopen[1], tc_.xaext[1], nI, nD, nopen);
 }
 
 // ---------------------------------------------------------------- k_traceback_wide
@@ -1174,10 +1193,15 @@ template <bool AFF>
 __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_pair_result *res)
 {
     constexpr uint32_t CSHIFT = AFF ? 2u : 4u, CMASK = AFF ? 3u : 15u, BITS = AFF ? 8u : 2u;
-    __shared__ int32_t sub[25];
+    __shared__ int32_t sub[25 * (1 + GBA_MAX_EXTRA)];
     __shared__ __attribute__((aligned(16))) uint32_t win[WT_WIN];
     __shared__ uint32_t tcw[WT_TC / 4];
-    if (threadIdx.x < 25) sub[threadIdx.x] = tc_.sub[threadIdx.x];
+    if (threadIdx.x < 25) {
+        sub[threadIdx.x] = tc_.sub[threadIdx.x];
+        for (int x = 0; x < GBA_MAX_EXTRA; x++) sub[25 * (x + 1) + threadIdx.x] = tc_.xsub[x][threadIdx.x];
+    }
+    const int nx = tc_.n_extra;
+    int32_t xs0 = 0, xs1 = 0, xp0 = 0, xp1 = 0;         // extra scorers: sums, and the lookups of the last diagonal move
     const int lane = threadIdx.x;
     const uint32_t p = d.order[d.plan->cls_base[CLS_WIDE] + blockIdx.x];
     if (d.status[p] != GBA_PAIR_OK) return;             // fill found the end cell unreachable
@@ -1229,6 +1253,8 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
             const uint32_t tb_v = tcw8[(int32_t)j - jb];
             const uint32_t aw = uni(aw_v), gup = uni(gup_v), tbase = uni(tb_v) - 1u;
             score += (int32_t)uni((uint32_t)pend_v); pend_v = 0;
+            if (nx > 0) { xs0 += (int32_t)uni((uint32_t)xp0); xp0 = 0; }
+            if (nx > 1) { xs1 += (int32_t)uni((uint32_t)xp1); xp1 = 0; }
             const uint32_t cell = aw >> ((k & CMASK) * BITS);
             // move: 0 diagonal, 1 up (insertion), 2 left (deletion), 3 none (state change only), 4 error
             uint32_t mv;
@@ -1249,6 +1275,8 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
                 const uint32_t qb = (gw >> 10) & 7u;
                 nM += qb == tbase ? 1u : 0u;
                 pend_v = sub[qb * 5 + tbase];         // added one step later: keeps the LDS read off the critical path
+                if (nx > 0) xp0 = sub[25 + qb * 5 + tbase];
+                if (nx > 1) xp1 = sub[50 + qb * 5 + tbase];
                 run++; ndiag++; prev_op = 0;
             } else {
                 if (run) {
@@ -1270,16 +1298,18 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
         }
     }
     score += (int32_t)uni((uint32_t)pend_v);
+    xs0 += (int32_t)uni((uint32_t)xp0); xs1 += (int32_t)uni((uint32_t)xp1);
     if (run) { outp -= 3; if (lane == 0) { outp[0] = i; outp[1] = j; outp[2] = run; } nb++; }
     if (lane != 0) return;
     gba_pair_result &R = res[p];
     if (!ok) { d.status[p] = GBA_PAIR_UNREACHABLE; return; }
     const uint32_t nI = Q - ndiag, nD = T - ndiag;
-    if (tc_.affine) score += (int32_t)nopen * tc_.aopen + (int32_t)(nI + nD) * tc_.aext;
-    else score += (int32_t)nI * tc_.ins + (int32_t)nD * tc_.del;
+    score += gap_score(tc_.affine, tc_.ins, tc_.del, tc_.aopen, tc_.aext, nI, nD, nopen);
     R.n_blk = nb; R.score = score;
     d.span[p] = nb;
     R.n_match = nM; R.n_mismatch = ndiag - nM; R.n_ins = nI; R.n_del = nD;
+    if (nx > 0) R.extra_score[0] = xs0 + gap_score(tc_.xaffine[0], tc_.xins[0], tc_.xdel[0], tc_.xaopen[0], tc_.xaext[0], nI, nD, nopen);
+    if (nx > 1) R.extra_score[1] = xs1 + gap_score(tc_.xaffine[1], tc_.xins[1], tc_.xdel[1], tc_.xaopen[1], tc_.xaext[1], nI, nD, nopen);
 }
 
 // ---------------------------------------------------------------- results
@@ -1747,6 +1777,7 @@ int gba_set_scoring(gba_ctx *c, const gba_scoring *s)
     if (!c || !s) return GBA_E_INVALID;
     if (s->mode != GBA_MODE_LINEAR && s->mode != GBA_MODE_KBAND && s->mode != GBA_MODE_AFFINE) return GBA_E_INVALID;
     if (s->tie_break != GBA_TIE_DIAG_LEFT_UP && s->tie_break != GBA_TIE_DIAG_UP_LEFT) return GBA_E_INVALID;
+    if (s->n_extra < 0 || s->n_extra > GBA_MAX_EXTRA) return GBA_E_INVALID;
     if (s->band < 0 || s->max_band < 0 || s->band > 30000 || s->max_band > 30000) return GBA_E_INVALID;
     if (s->mode == GBA_MODE_KBAND && (s->kband_k < 0 || s->kband_k > 30000)) return GBA_E_INVALID;
     // The fill kernels keep substitution costs in a +128-biased byte table and cell words in int32
@@ -1788,6 +1819,14 @@ int gba_set_scoring(gba_ctx *c, const gba_scoring *s)
     for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) t.sub[a * 5 + b] = s->sub[a][b];
     t.ins = s->stats_ins; t.del = s->stats_del; t.aopen = s->stats_affine_open; t.aext = s->stats_affine_extend;
     t.affine = s->stats_affine; t.codeU = codeU; t.codeL = codeL; t.mode = s->mode;
+    t.n_extra = s->n_extra;
+    for (int x = 0; x < GBA_MAX_EXTRA; x++) {
+        const gba_rescorer &r = s->extra[x];
+        const bool on = x < s->n_extra;
+        for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) t.xsub[x][a * 5 + b] = on ? r.sub[a][b] : 0;
+        t.xins[x] = on ? r.ins : 0; t.xdel[x] = on ? r.del : 0;
+        t.xaopen[x] = on ? r.affine_open : 0; t.xaext[x] = on ? r.affine_extend : 0; t.xaffine[x] = on ? r.affine : 0;
+    }
     c->have_scoring = true;
     return GBA_OK;
 }

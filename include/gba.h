@@ -69,6 +69,19 @@ typedef struct {
  * (iblasr/MappingParameters.h:207-381) plus the 5x5 SMRTDistanceMatrix as main()
  * leaves it (Blasr.cpp:910-937).  Lower scores are better.
  */
+/* An additional scorer the finished path is rescored with (ComputeAlignmentScore of the
+ * reference): the probability score of the mapping-quality step, which rescores every refined
+ * alignment with SMRTLogProbMatrix and the affine costs (iblasr/BlasrUtilsImpl.hpp:120-151), and
+ * the edit distance of the SAM/BAM writers (EditDistanceMatrix, 1, 1; :1056-1063). */
+typedef struct {
+    int32_t sub[5][5];
+    int32_t ins, del;                     /* per gap base */
+    int32_t affine_open, affine_extend;   /* used instead when `affine` is nonzero: open + length*extend per gap run */
+    int32_t affine;
+} gba_rescorer;
+
+#define GBA_MAX_EXTRA 2
+
 typedef struct {
     int32_t sub[5][5];          /* [query code][target code], codes A,C,G,T,N = 0..4 */
     int32_t ins, del;           /* DP cost of a query base against a gap / a target base against a gap */
@@ -80,6 +93,8 @@ typedef struct {
     int32_t tie_break;          /* GBA_TIE_* */
     int32_t kband_k;            /* GBA_MODE_KBAND: half-width of the diagonal band */
     int32_t stats_affine;       /* nonzero: rescoring charges each gap run open + length*extend */
+    int32_t n_extra;            /* 0..GBA_MAX_EXTRA further scorers, results in gba_pair_result.extra_score */
+    gba_rescorer extra[GBA_MAX_EXTRA];
 } gba_scoring;
 
 /* one gap-free run of the alignment: the reference's blasr::Block (BlasrUtilsImpl.hpp:745-746) */
@@ -124,6 +139,7 @@ typedef struct {
     uint32_t n_match, n_mismatch, n_ins, n_del;
     uint32_t rows, cols;        /* query / target bases inside the DP region */
     uint64_t ncells;            /* refinedAlignment.nCells: sum over guide rows of tPre+tPost+1 */
+    int32_t extra_score[GBA_MAX_EXTRA];   /* the path under gba_scoring.extra[] */
 } gba_pair_result;
 
 typedef struct {

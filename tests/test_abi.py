@@ -35,9 +35,10 @@ def test_version_and_strerror():
 
 def test_struct_layouts():
     from blasr_amd import _lib
-    assert _lib.PAIR_RESULT_DT.itemsize == 64
+    assert _lib.PAIR_RESULT_DT.itemsize == 72
     assert _lib.BLOCK_DT.itemsize == 12
-    assert C.sizeof(_lib.Scoring) == (25 + 14) * 4
+    assert C.sizeof(_lib.Rescorer) == (25 + 5) * 4
+    assert C.sizeof(_lib.Scoring) == (25 + 14 + 1 + 2 * 30) * 4
     assert C.sizeof(_lib.Batch) == 8 + 9 * 8 + 3 * 8 + 8
     assert C.sizeof(_lib.Results) == 32
 

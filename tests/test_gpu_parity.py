@@ -354,3 +354,45 @@ def test_split_batches(api, oracle, synth, monkeypatch):
             _run(c2, api, oracle, batch, **kw)
     finally:
         c2.close()
+
+
+def test_extra_rescoring_scorers(ctx, api, oracle, synth):
+    """The path rescored with further scorers (the reference's probability score and edit distance,
+    iblasr/BlasrUtilsImpl.hpp:120-151, :1056-1063).  One extra scorer repeats the stats scorer with
+    affine gap runs, so it must equal `score` (which the oracle checks); the other is a random
+    matrix with linear gaps, recomputed here from the blocks; a third run checks the edit distance."""
+    from blasr_amd import _lib
+    rng = np.random.default_rng(5)
+    batch = synth.generate(200, read_len=1500, len_jitter=800, seed=91, decoy_every=9)
+    code = np.full(256, 4, np.int64)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i; code[ch + 32] = i
+    for mode, band in ((_lib.MODE_LINEAR, 10), (_lib.MODE_LINEAR, 90), (_lib.MODE_AFFINE, 16)):
+        kw = dict(mode=mode, band=band, stats_affine=1, stats_affine_open=6, stats_affine_extend=2)
+        dp = [[(0 if a == 4 or b == 4 else -5 if a == b else 6) for b in range(5)] for a in range(5)]
+        m1 = rng.integers(-40, 40, size=(5, 5))
+        extra = [dict(sub=m1.tolist(), ins=3, dele=8), dict(sub=dp, affine=1, affine_open=6, affine_extend=2)]
+        ctx.set_scoring(api.make_scoring(extra=extra, **kw))
+        got, gb, rc = ctx.refine_host(batch)
+        assert rc == 0
+        util.compare_batch(oracle, batch, oracle.make_params(**kw), got, gb, None)
+        ok = got["status"] == 0
+        assert ok.sum() > 100
+        assert np.array_equal(got["extra_score"][ok, 1], got["score"][ok])
+        for p in np.flatnonzero(ok)[:80]:
+            k = got[p]
+            blk = gb[int(k["blk_off"]):int(k["blk_off"]) + int(k["n_blk"])]
+            q0 = int(batch["q_off"][p]) + int(k["q_pos"]); t0 = int(batch["t_off"][p]) + int(k["t_pos"])
+            sc = 3 * int(k["n_ins"]) + 8 * int(k["n_del"])
+            for b in blk:
+                bq, bt, ln = int(b["q_pos"]), int(b["t_pos"]), int(b["length"])
+                qs = code[batch["q_arena"][q0 + bq:q0 + bq + ln]]; ts = code[batch["t_arena"][t0 + bt:t0 + bt + ln]]
+                sc += int(m1[qs, ts].sum())
+            assert sc == int(k["extra_score"][0]), (p, sc, int(k["extra_score"][0]))
+    # edit distance: mismatches + gap bases
+    edit = [[0 if a == b else 1 for b in range(5)] for a in range(5)]
+    ctx.set_scoring(api.make_scoring(extra=[dict(sub=edit, ins=1, dele=1)]))
+    got, gb, rc = ctx.refine_host(batch)
+    ok = got["status"] == 0
+    nm = got["n_mismatch"].astype(np.int64) + got["n_ins"] + got["n_del"]
+    assert np.array_equal(got["extra_score"][ok, 0], nm[ok]) and not got["extra_score"][ok, 1].any()
