@@ -6,7 +6,7 @@ adversarial pairs whose guides are random increasing blocks over random sequence
 scoring / band / mode parameters, runs both sides and compares every result field and every block.
 Mismatches are written to gpurun_out/fuzz_fail_<k>.json with everything needed to replay them.
 
-usage: python tools/fuzz_gpu.py [--seconds 120] [--seed 1]
+usage: python tests/fuzz_gpu.py [--seconds 120] [--seed 1]
 """
 import argparse
 import json
@@ -19,7 +19,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 FIELDS = ("status", "dp_score", "score", "q_pos", "t_pos", "n_blk", "n_match", "n_mismatch",
           "n_ins", "n_del", "rows", "cols", "ncells")

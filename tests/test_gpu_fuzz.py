@@ -1,4 +1,4 @@
-"""Short run of the randomised differential test (tools/fuzz_gpu.py): random workloads, random
+"""Short run of the randomised differential test (tests/fuzz_gpu.py): random workloads, random
 scoring / band / mode, libgba through the C ABI against the oracle."""
 import os
 import subprocess
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_fuzz_short():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "--seconds", "10", "--seed", "12345"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_gpu.py"), "--seconds", "10", "--seed", "12345"],
                        capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "fails 0" in r.stdout
