@@ -53,6 +53,24 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def make_batch_struct(batch):
+    """gba_batch over the numpy arrays of a host batch dict.  Returns (Batch, dict of the arrays the
+    struct points into — keep it alive as long as the struct is used)."""
+    n = int(batch["n_pairs"])
+    keep = {k: np.ascontiguousarray(batch[k], dtype=dt) for k, dt in (
+        ("q_arena", np.uint8), ("t_arena", np.uint8), ("blocks", BLOCK_DT),
+        ("q_off", np.uint64), ("t_off", np.uint64), ("blk_off", np.uint64),
+        ("q_len", np.uint32), ("t_len", np.uint32), ("n_blk", np.uint32), ("t_rc", np.uint8))
+        if batch.get(k) is not None}
+    ta = keep.get("t_arena")          # absent: windows of the reference given to set_reference
+    b = Batch(n, _ptr(keep["q_arena"]), _ptr(keep["q_off"]), _ptr(keep["q_len"]),
+              _ptr(ta) if ta is not None else None, _ptr(keep["t_off"]), _ptr(keep["t_len"]),
+              _ptr(keep["blocks"]), _ptr(keep["blk_off"]), _ptr(keep["n_blk"]),
+              keep["q_arena"].size, ta.size if ta is not None else 0, keep["blocks"].size,
+              _ptr(keep["t_rc"]) if "t_rc" in keep else None)
+    return b, keep
+
+
 class Context:
     def __init__(self, device=0, timing=False, stream=None):
         self._L = _lib.lib()
@@ -102,17 +120,7 @@ class Context:
         """batch: dict of numpy arrays (see blasr_amd.synth.generate).  Returns
         (pairs ndarray[PAIR_RESULT_DT], blocks ndarray[BLOCK_DT], rc)."""
         n = int(batch["n_pairs"])
-        keep = {k: np.ascontiguousarray(batch[k], dtype=dt) for k, dt in (
-            ("q_arena", np.uint8), ("t_arena", np.uint8), ("blocks", BLOCK_DT),
-            ("q_off", np.uint64), ("t_off", np.uint64), ("blk_off", np.uint64),
-            ("q_len", np.uint32), ("t_len", np.uint32), ("n_blk", np.uint32), ("t_rc", np.uint8))
-            if batch.get(k) is not None}
-        ta = keep.get("t_arena")          # absent: windows of the reference given to set_reference
-        b = Batch(n, _ptr(keep["q_arena"]), _ptr(keep["q_off"]), _ptr(keep["q_len"]),
-                  _ptr(ta) if ta is not None else None, _ptr(keep["t_off"]), _ptr(keep["t_len"]),
-                  _ptr(keep["blocks"]), _ptr(keep["blk_off"]), _ptr(keep["n_blk"]),
-                  keep["q_arena"].size, ta.size if ta is not None else 0, keep["blocks"].size,
-                  _ptr(keep["t_rc"]) if "t_rc" in keep else None)
+        b, keep = make_batch_struct(batch)
         self._check(self._L.gba_submit(self._h, C.byref(b)))
         if blocks_capacity is None:
             blocks_capacity = int(keep["q_len"].astype(np.uint64).sum()) + n

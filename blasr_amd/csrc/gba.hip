@@ -1410,6 +1410,7 @@ struct gba_ctx {
     bool own_stream = false;
     int last_hip = 0;
     bool have_scoring = false;
+    bool lds_attr_set = false;       // the fill kernels' dynamic-LDS limit has been raised on this device
     gba_scoring sc;
     FillConst fc;
     TbConst tbc;
@@ -1463,14 +1464,13 @@ int launch_fill(gba_ctx *c, const Dev &d, uint32_t cls, uint32_t count, hipStrea
     const bool aff = c->sc.mode == GBA_MODE_AFFINE;
     const size_t rings = aff ? 2 : 1;
     const size_t lds = (rings * (slots + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!c->lds_attr_set) {                     // per device, and a ctx lives on one device
         const size_t mx1 = ((size_t)(cls_slots(LANE_CLS_LINEAR - 1) + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
         const size_t mx2 = (2 * (size_t)(cls_slots(LANE_CLS_AFFINE - 1) + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
         const size_t mx = mx1 > mx2 ? mx1 : mx2;
         HIPCHK(c, hipFuncSetAttribute((const void *)k_fill<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_fill<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
-        attr_set = true;
+        c->lds_attr_set = true;
     }
     if (aff) hipLaunchKernelGGL(k_fill<true>, dim3((count + 63) / 64), dim3(64), lds, st, d, c->fc, cls, slots);
     else hipLaunchKernelGGL(k_fill<false>, dim3((count + 63) / 64), dim3(64), lds, st, d, c->fc, cls, slots);
@@ -1591,6 +1591,13 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
     HIPCHK(c, hipEventRecord(sl.t_tb1, s));
     HIPCHK(c, hipEventRecord(sl.ev_done, s));
     return GBA_OK;
+}
+
+// A batch with pairs must bring every array the kernels index (the target arena may be absent:
+// windows of the ctx reference; the strand flags are optional).
+bool batch_complete(const gba_batch *b)
+{
+    return b->n_pairs == 0 || (b->q_arena && b->blocks && b->q_off && b->t_off && b->blk_off && b->q_len && b->t_len && b->n_blk);
 }
 
 // Runs one batch whose inputs and outputs are device pointers.  With GBA_SPLIT_MIN set, a batch of
@@ -1787,6 +1794,15 @@ int gba_set_scoring(gba_ctx *c, const gba_scoring *s)
         for (int b = 0; b < 5; b++)
             if (s->sub[a][b] < -128 || s->sub[a][b] > 127) return GBA_E_UNSUPPORTED;
     if (s->ins < -127 || s->ins > 127 || s->del < -127 || s->del > 127) return GBA_E_UNSUPPORTED;
+    if (s->mode == GBA_MODE_AFFINE) {
+        // affine words keep one more tag bit: half the cost range (and k_meta half the row count)
+        const int32_t oe = s->affine_open + s->affine_extend;
+        for (int a = 0; a < 5; a++)
+            for (int b = 0; b < 5; b++)
+                if (s->sub[a][b] < -63 || s->sub[a][b] > 63) return GBA_E_UNSUPPORTED;
+        if (s->affine_extend < 0 || s->affine_extend > 63 || oe < 0 || oe > 63) return GBA_E_UNSUPPORTED;
+    }
+    // nothing of the ctx changes before this point: a refused scoring leaves the previous one in force
     c->sc = *s;
     const uint32_t codeL = s->tie_break == GBA_TIE_DIAG_LEFT_UP ? 1u : 2u, codeU = 3u - codeL;
     FillConst &f = c->fc;
@@ -1800,12 +1816,7 @@ int gba_set_scoring(gba_ctx *c, const gba_scoring *s)
     const int SH = s->mode == GBA_MODE_AFFINE ? 6 : 5;
     const int32_t bias = 128 << SH;
     if (s->mode == GBA_MODE_AFFINE) {
-        // affine words keep one more tag bit: halve the cost range (and k_meta the row count)
         const int32_t oe = s->affine_open + s->affine_extend;
-        for (int a = 0; a < 5; a++)
-            for (int b = 0; b < 5; b++)
-                if (s->sub[a][b] < -63 || s->sub[a][b] > 63) return GBA_E_UNSUPPORTED;
-        if (s->affine_extend < 0 || s->affine_extend > 63 || oe < 0 || oe > 63) return GBA_E_UNSUPPORTED;
         f.cIO = oe * 64 + bias; f.cIE = s->affine_extend * 64 + bias + 4;
         f.cDO = oe * 64; f.cDE = s->affine_extend * 64 + 2;
         f.diag0 = -((s->sub[4][4] + 128) * 64);
@@ -1836,6 +1847,8 @@ int gba_submit_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     if (!c || !b || !out) return GBA_E_INVALID;
     if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
     if (b->n_pairs && (!out->pairs || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
+    if (!batch_complete(b)) return GBA_E_INVALID;
+    if (!b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
     return run_device(c, b, out);
 }
 
@@ -1843,6 +1856,8 @@ int gba_submit(gba_ctx *c, const gba_batch *b)
 {
     if (!c || !b) return GBA_E_INVALID;
     if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
+    if (!batch_complete(b)) return GBA_E_INVALID;
+    if (b->n_pairs && !b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
     const uint32_t n = b->n_pairs;
     HIPCHK(c, hipSetDevice(c->device));
     c->flight_n = n; c->flight_rc = GBA_OK; c->flight_needed = 0;

@@ -167,13 +167,18 @@ int gba_create(gba_ctx **out, const gba_config *cfg);
 void gba_destroy(gba_ctx *ctx);
 
 /* Replaces building distScoreFn / distScoreFn2 and choosing kernel and band
- * (BlasrUtilsImpl.hpp:630-646, :705-731). */
+ * (BlasrUtilsImpl.hpp:630-646, :705-731).  GBA_E_INVALID for values outside the
+ * enums / ranges, GBA_E_UNSUPPORTED for costs the kernels' word format cannot
+ * hold; either way the scoring set before stays in force. */
 int gba_set_scoring(gba_ctx *ctx, const gba_scoring *s);
 
 /* Replaces the RefineAlignments loop over candidates (BlasrUtilsImpl.hpp:911-914)
  * for a whole batch.  gba_submit copies the host batch to the device and starts
  * it; gba_wait blocks, copies results into out->pairs / out->blocks (host
- * buffers) and returns GBA_OK or GBA_E_NOSPACE. */
+ * buffers) and returns GBA_OK or GBA_E_NOSPACE.  A batch with pairs must bring
+ * every array except t_arena (NULL: windows of the reference) and t_rc:
+ * GBA_E_INVALID otherwise; GBA_E_STATE without scoring, with a batch in flight,
+ * or with a NULL t_arena and no reference. */
 int gba_submit(gba_ctx *ctx, const gba_batch *host_batch);
 int gba_wait(gba_ctx *ctx, gba_results *out);
 

@@ -246,11 +246,37 @@ def test_host_nospace_and_reuse(ctx, api, oracle, synth):
     assert (p3["status"] == _lib.PAIR_NOSPACE).sum() > 100
 
 
-def test_unsupported_scoring_is_refused(ctx, api):
+def test_unsupported_scoring_is_refused(ctx, api, oracle, synth):
+    """A refused scoring leaves the previous one in force, whichever check refuses it."""
     from blasr_amd import _lib
-    with pytest.raises(_lib.GbaError):
-        ctx.set_scoring(api.make_scoring(mismatch=500))
+    batch = synth.generate(40, read_len=400, seed=31)
+    kw = dict(match=-4, mismatch=7, ins=6, dele=3)
+    ctx.set_scoring(api.make_scoring(**kw))
+    for bad in (dict(mismatch=500), dict(mode=_lib.MODE_AFFINE, mismatch=100),
+                dict(mode=_lib.MODE_AFFINE, affine_open=60, affine_extend=10)):
+        with pytest.raises(_lib.GbaError) as e:
+            ctx.set_scoring(api.make_scoring(**bad))
+        assert e.value.code == _lib.E_UNSUPPORTED
+        pairs, blocks, rc = ctx.refine_host(batch)
+        assert rc == 0
+        util.compare_batch(oracle, batch, oracle.make_params(**kw), pairs, blocks)
     ctx.set_scoring(api.make_scoring())
+
+
+def test_incomplete_batch_is_refused(ctx, api, synth):
+    """Missing arrays are an argument error, not a crash; no reference set is a sequence error."""
+    import ctypes as C
+    from blasr_amd import _lib
+    ctx.set_scoring(api.make_scoring())
+    batch = synth.generate(4, read_len=100, seed=5)
+    b, keep = api.make_batch_struct(batch)
+    b.q_len = None
+    assert _lib.lib().gba_submit(ctx._h, C.byref(b)) == _lib.E_INVALID
+    b, keep = api.make_batch_struct(batch)
+    b.t_arena = None
+    assert _lib.lib().gba_submit(ctx._h, C.byref(b)) == _lib.E_STATE
+    pairs, blocks, rc = ctx.refine_host(batch)          # the ctx is still usable
+    assert rc == 0 and (pairs["status"] == 0).all()
 
 
 def test_full_size_properties(ctx, api, oracle, synth):
