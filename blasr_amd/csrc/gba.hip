@@ -76,7 +76,7 @@ struct Dev {                  // per-batch device state, SoA per pair
     uint32_t n;
     // inputs (device pointers)
     const uint8_t *q_arena, *t_arena, *t_rc;
-    uint64_t t_arena_bytes;   // extent of t_arena when it is the ctx reference (windows are checked against it), else 0
+    uint64_t q_arena_bytes, t_arena_bytes, n_blocks_total;   // extents of the three arenas: every pair's slices are checked against them
     const uint64_t *q_off, *t_off, *blk_off;
     const uint32_t *q_len, *t_len, *n_blk;
     const gba_block *blocks;
@@ -142,15 +142,21 @@ __global__ void k_meta(Dev d, int mode, int kband_k)
     uint64_t drift_sum = 0;
     const uint32_t ql = d.q_len[p], tl = d.t_len[p];
     uint32_t nb = 0;
-    if (d.t_arena_bytes && d.t_off[p] + tl > d.t_arena_bytes) st = GBA_PAIR_BAD_GUIDE;     // window outside the reference
+    // slices that leave their arena (a window outside the reference, a corrupt offset) are never touched
+    const uint64_t qo = d.q_off[p], to = d.t_off[p];
+    if (to > d.t_arena_bytes || tl > d.t_arena_bytes - to || qo > d.q_arena_bytes || ql > d.q_arena_bytes - qo)
+        st = GBA_PAIR_BAD_GUIDE;
     if (mode == GBA_MODE_KBAND) {
         Q = ql; T = tl;
         int64_t dd = (int64_t)tl - (int64_t)ql;
         if (dd < 0) dd = -dd;
-        if (dd > kband_k) st = GBA_PAIR_END_OUT_OF_BAND;
+        if (st == GBA_PAIR_OK && dd > kband_k) st = GBA_PAIR_END_OUT_OF_BAND;
     } else {
         nb = d.n_blk[p];
+        const uint64_t bo = d.blk_off[p];
         if (nb == 0) st = GBA_PAIR_EMPTY_GUIDE;
+        else if (bo > d.n_blocks_total || nb > d.n_blocks_total - bo) { st = GBA_PAIR_BAD_GUIDE; nb = 0; }
+        else if (st != GBA_PAIR_OK) nb = 0;
         else {
             const gba_block *bl = d.blocks + d.blk_off[p];
             uint64_t qe = 0, te = 0;
@@ -1619,6 +1625,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     g.n = n;
     g.q_arena = b->q_arena; g.t_arena = b->t_arena; g.blocks = b->blocks;
     g.t_rc = b->t_rc;
+    g.q_arena_bytes = b->q_arena_bytes; g.t_arena_bytes = b->t_arena_bytes; g.n_blocks_total = b->n_blocks_total;
     if (!g.t_arena) {            // targets are windows of the ctx reference
         if (!c->b_ref.ptr) return GBA_E_STATE;
         g.t_arena = (const uint8_t *)c->b_ref.ptr; g.t_arena_bytes = c->ref_len;
@@ -1873,9 +1880,12 @@ int gba_submit(gba_ctx *c, const gba_batch *b)
         if ((rc = ensure(c, *x.buf, x.bytes + 16))) return rc;
         if (x.bytes) HIPCHK(c, hipMemcpyAsync(x.buf->ptr, x.src, x.bytes, hipMemcpyHostToDevice, c->stream));
     }
-    // worst case one block per query base
+    // worst case one block per base of the shorter sequence (lengths that cannot be real count as 0)
     uint64_t cap = 0;
-    for (uint32_t p = 0; p < n; p++) cap += (uint64_t)b->q_len[p] + 1;
+    for (uint32_t p = 0; p < n; p++) {
+        const uint64_t ql = b->q_len[p] <= b->q_arena_bytes ? b->q_len[p] : 0, tl = b->t_len[p];
+        cap += (ql < tl ? ql : tl) + 1;
+    }
     if ((rc = ensure(c, c->s_res, (size_t)n * sizeof(gba_pair_result)))) return rc;
     if ((rc = ensure(c, c->s_out, (size_t)cap * sizeof(gba_block)))) return rc;
     gba_batch db = *b;

@@ -279,6 +279,37 @@ def test_incomplete_batch_is_refused(ctx, api, synth):
     assert rc == 0 and (pairs["status"] == 0).all()
 
 
+def test_slices_outside_their_arenas(ctx, api, oracle, synth):
+    """Offsets or lengths that leave an arena give that pair BAD_GUIDE; nothing is read there and
+    the other pairs are unaffected."""
+    from blasr_amd import _lib
+    batch = synth.generate(64, read_len=300, seed=9)
+    ctx.set_scoring(api.make_scoring())
+    good, gblocks, rc = ctx.refine_host(batch)
+    bad = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()}
+    bad["q_off"][3] = np.uint64(1) << np.uint64(40)
+    bad["t_off"][7] = np.uint64(len(batch["t_arena"]) - 5)
+    bad["blk_off"][11] = np.uint64(len(batch["blocks"]))
+    bad["q_len"][13] = np.uint32(0xfffffff0)
+    bad["t_off"][17] = np.uint64(0xffffffffffffff00)
+    pairs, blocks, rc = ctx.refine_host(bad, blocks_capacity=len(gblocks))
+    assert rc == 0
+    hit = [3, 7, 11, 13, 17]
+    assert (pairs["status"][hit] == _lib.PAIR_BAD_GUIDE).all()
+    rest = np.setdiff1d(np.arange(64), hit)
+    for f in util.FIELDS:
+        assert np.array_equal(pairs[f][rest], good[f][rest]), f
+    for p in rest:
+        a = blocks[int(pairs["blk_off"][p]):int(pairs["blk_off"][p]) + int(pairs["n_blk"][p])]
+        b = gblocks[int(good["blk_off"][p]):int(good["blk_off"][p]) + int(good["n_blk"][p])]
+        assert np.array_equal(a, b)
+    for mode_kw in (dict(mode=_lib.MODE_KBAND, kband_k=40),):
+        ctx.set_scoring(api.make_scoring(**mode_kw))
+        pairs, blocks, rc = ctx.refine_host(bad, blocks_capacity=int(batch["q_len"].sum()) + 64)
+        assert rc == 0 and (pairs["status"][[3, 7, 13, 17]] != _lib.PAIR_OK).all()
+    ctx.set_scoring(api.make_scoring())
+
+
 def test_full_size_properties(ctx, api, oracle, synth):
     """Benchmark-sized pairs: size-independent invariants on all pairs, oracle parity on a sample."""
     batch, cfg = synth.preset("c2_10kb_linear", 2048)
