@@ -310,6 +310,29 @@ def test_slices_outside_their_arenas(ctx, api, oracle, synth):
     ctx.set_scoring(api.make_scoring())
 
 
+def test_many_short_pairs(ctx, api, oracle, synth):
+    """150 000 pairs in one batch: the single-block scans and the class counters over many iterations."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = 150_000
+    batch = synth.generate(n, read_len=120, len_jitter=60, seed=4, ref_len=500_000, min_block=5,
+                           p_ins=0.03, p_del=0.02, p_sub=0.01)
+    ctx.set_scoring(api.make_scoring())
+    pairs, blocks, rc = ctx.refine_host(batch)
+    assert rc == 0
+    P = oracle.make_params()
+    chunk = n // 8
+    with ThreadPoolExecutor(8) as pool:
+        parts = list(pool.map(lambda f: oracle.align_batch(batch, P, f, min(chunk, n - f)), range(0, n, chunk)))
+    ores = np.concatenate([r for r, _ in parts])
+    assert np.array_equal(ores["status"], pairs["status"])
+    for f in util.FIELDS:
+        assert np.array_equal(ores[f].astype(np.int64), pairs[f].astype(np.int64)), f
+    ob = np.concatenate([x for _, bl in parts for x in bl if len(x)])
+    assert len(ob) == len(blocks)
+    for f in ("q_pos", "t_pos", "length"):
+        assert np.array_equal(ob[f], blocks[f]), f
+
+
 def test_full_size_properties(ctx, api, oracle, synth):
     """Benchmark-sized pairs: size-independent invariants on all pairs, oracle parity on a sample."""
     batch, cfg = synth.preset("c2_10kb_linear", 2048)
