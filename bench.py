@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=106496, help="pairs per GPU per step")
     ap.add_argument("--workload", default="c2_10kb_linear")
     ap.add_argument("--band", type=int, default=None, help="override the preset's band")
+    ap.add_argument("--max-band", type=int, default=250, help="cap of the widened band in guide gaps (experiments)")
     ap.add_argument("--streams", type=int, default=1, help="contexts per GPU, each on its own stream with pairs/streams pairs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -103,7 +104,7 @@ def main():
     if args.band is not None:
         cfg["band"] = args.band
     affine = cfg["mode"] == "affine"
-    scoring = api.make_scoring(band=cfg["band"], mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR)
+    scoring = api.make_scoring(band=cfg["band"], max_band=args.max_band, mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR)
     for i in range(S):
         c2 = dict(cfg); c2["seed"] = cfg["seed"] + 104729 * i
         h = synth.generate(per[i], **c2)

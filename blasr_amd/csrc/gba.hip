@@ -561,11 +561,15 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
 // of 3 / 8 entering columns), which is why a pair's widest shift + width must stay SPAN_MARGIN
 // below the ring size.
 //
-// Guide words arrive through a 12-word LDS ring per lane, refilled every 4th step with a 4-word
-// group that is requested at the start of that step and installed at its end; that wait is the
-// only vector-memory wait in the loop.  Record dwords are stored directly.
-constexpr int FIFO_WORDS = 12;
-constexpr int LDS_TAB = 16, LDS_FIFO = FIFO_WORDS * 64;
+// Guide words are read in 16-byte groups into registers: group A holds the unread words (A.x is
+// the next one; a pop shifts the group down), group B is the group after it.  When a pop empties
+// A, B takes its place and the lane requests the following group into B.  The request is one
+// inline-asm block at the top level of the loop that narrows EXEC to the requesting lanes itself
+// (inside a C++ branch the compiler gives the load a scratch destination and copies it into B at
+// the end of the branch, before the data has arrived); it is waited for at the end of the step,
+// the only vector-memory wait in the loop, a whole step before B can be needed.  Record dwords
+// are stored directly.  No LDS is spent on the stream: LDS is what limits the waves per CU.
+constexpr int LDS_TAB = 16;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // Affine variant (AFF): the match state M and the insertion-gap state I of the previous row both
@@ -576,13 +580,18 @@ template <bool AFF>
 __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, uint32_t slots)
 {
     extern __shared__ uint32_t smem[];
+    // Two waves of this kernel saturate a SIMD and a third one only makes all three slower (a launch
+    // lasts as long as its busiest SIMD), but LDS would admit a third on some SIMDs.  Claiming 200
+    // of the SIMD's 512 VGPRs per wave makes the hardware place at most two fill waves on a SIMD and
+    // leaves room for a wave of another kernel (the tracebacks of other classes run beside the fill).
+    asm volatile("" ::: "v199");
     constexpr int SH = AFF ? 6 : 5;                     // score shift of a cell word
     constexpr uint32_t TAGS = (1u << SH) - 1u;
     constexpr int CAP = AFF ? CAP_AFFINE : CAP_LINEAR;
     constexpr int NAR = AFF ? CAP / 4 : CAP / 16;       // record dwords of one step
     const int lane = threadIdx.x;
     const uint32_t SL = slots + PAD_SLOTS;              // slots of one ring
-    uint32_t *tab = smem, *fifo = smem + LDS_TAB, *lds = smem + LDS_TAB + LDS_FIFO;
+    uint32_t *tab = smem, *lds = smem + LDS_TAB;
     const uint32_t IOFF = SL * 64;                      // dword offset of the I ring
     if (lane < 10) tab[lane] = fc.mrow[lane];
     __syncthreads();
@@ -601,16 +610,15 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     char *recb = (char *)(d.rec + rbase);
     uint32_t rob = (uint32_t)(d.rec_off[p] - rbase) * 4u;
 
-    // FIFO: stream words [wc, wi) are in the LDS ring; hs / is are the ring slots of words wc / wi.
-    // At least two words are buffered at the start of every step (see the refill rule below), so
-    // the word after the one a step pops can be peeked during that step.
-    uint32_t wc = 0, wi = FIFO_WORDS, hs = 0, is = 0;
-    {
-        const uint4 a = *(const uint4 *)(st), b = *(const uint4 *)(st + 4), c4 = *(const uint4 *)(st + 8);
-        uint32_t *f = fifo + lane;
-        f[0] = a.x; f[64] = a.y; f[128] = a.z; f[192] = a.w; f[256] = b.x; f[320] = b.y; f[384] = b.z; f[448] = b.w;
-        f[512] = c4.x; f[576] = c4.y; f[640] = c4.z; f[704] = c4.w;
-    }
+    // stream words: A = unread words of the current group (na of them, A.x next), B = the group
+    // after it, wi = index of the first word not yet requested.  Every stream holds at least 16 words.
+    u32x4 A = *(const u32x4 *)(st), B = *(const u32x4 *)(st + 4);
+    uint32_t na = 4, wi = 8;
+    // No pair needs more steps than stream words plus one step per CAP cells; the loop stops there
+    // whatever the stream holds.
+    uint32_t max_steps = wcap + (uint32_t)(d.ncells[p] / (uint32_t)CAP) + 16u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) max_steps = max(max_steps, (uint32_t)__shfl_xor((int)max_steps, o, 64));
 
     uint32_t rows_left = live ? Q + 1 : 0;              // rows not yet started
     uint32_t W = 0, dsh = 0, k0 = 0, Wp = 0;            // current row: width, shift, cells done; previous width
@@ -618,27 +626,14 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     uint32_t diag = INFW, left = INFW, leftD = INFW, mlo = 0, mhi = 0, meta = 0;
     bool first = true, finished = !live;
     uint32_t final_word = INFW;
-    // the next word of the stream and the matrix row of its query base are fetched one step ahead
-    uint32_t nword = fifo[lane];                       // ring slot hs = 0
-    uint32_t nmlo = tab[((nword >> 10) & 7u) * 2], nmhi = tab[((nword >> 10) & 7u) * 2 + 1];
+    // the matrix row of the next word's query base is fetched one step ahead
+    uint32_t nmlo = tab[((A.x >> 10) & 7u) * 2], nmhi = tab[((A.x >> 10) & 7u) * 2 + 1];
 
-    for (uint32_t it = 0; __any(!finished); it++) {
-        // Refill (every 4th step): a lane with at most 8 of its 12 ring words left requests the next
-        // 4-word group now and installs it at the end of this step; a step pops at most one word, so
-        // a lane never starts a step with fewer than two.  The load is issued from inline asm so
-        // that no wait for it (or for the record stores) is placed anywhere else in the loop.
-        const bool refill = (it & 3u) == 0u && wi - wc <= 8u && wi + 4u <= wcap;
-        u32x4 pf = {0, 0, 0, 0};
-        if ((it & 3u) == 0u) {
-            if (refill) {
-                const uint32_t *src = st + wi;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pf) : "v"(src) : "memory");
-            }
-        }
+    for (uint32_t it = 0; it < max_steps && __any(!finished); it++) {
         // ---- 1. word pop
         const bool pop_ext = !finished && ext_left > 0u;
         const bool pop_row = !finished && ext_left == 0u && k0 >= W && rows_left > 0u;
-        const uint32_t word = nword;
+        const uint32_t word = A.x;
         if (pop_row) {
             rows_left--;
             Wp = W;
@@ -665,10 +660,25 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
             }
             newslot += 8u;
         }
-        if (pop_row || pop_ext) { wc++; hs = hs == FIFO_WORDS - 1 ? 0u : hs + 1u; }
-        // peek the following word (not needed before the next step); the matrix row of its query
-        // base is looked up after the cells, when the word has long arrived
-        nword = fifo[hs * 64 + lane];
+        uint32_t req = 0;
+        if (pop_row || pop_ext) {
+            A.x = A.y; A.y = A.z; A.z = A.w;
+            if (--na == 0u) {
+                A = B; na = 4;
+                req = wi + 4u <= wcap ? 1u : 0u;
+            }
+        }
+        {
+            const uint32_t *src = st + wi;
+            uint64_t saved;
+            asm volatile("s_mov_b64 %[sv], exec\n\t"
+                         "v_cmp_ne_u32_e32 vcc, 0, %[rq]\n\t"
+                         "s_and_b64 exec, exec, vcc\n\t"
+                         "global_load_dwordx4 %[b], %[sp], off\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [b] "+v"(B), [sv] "=&s"(saved) : [rq] "v"(req), [sp] "v"(src) : "vcc", "scc", "memory");
+            wi += req * 4u;
+        }
         // ---- 2. up to CAP cells of the current row, in groups of 8
         const bool did = !finished && ext_left == 0u && k0 < W;
         const uint32_t rem = W - k0;
@@ -746,17 +756,10 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                 }
             }
         }
-        nmlo = tab[((nword >> 10) & 7u) * 2]; nmhi = tab[((nword >> 10) & 7u) * 2 + 1];
-        // the refill is installed before this step's record stores are issued, so that its wait
-        // only covers the load (requested a whole step ago) and older stores
-        if ((it & 3u) == 0u) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf) : : "memory");
-            if (refill) {
-                uint32_t *f = fifo + is * 64 + lane;
-                f[0] = pf.x; f[64] = pf.y; f[128] = pf.z; f[192] = pf.w;
-                wi += 4; is = is == FIFO_WORDS - 4 ? 0u : is + 4u;
-            }
-        }
+        nmlo = tab[((A.x >> 10) & 7u) * 2]; nmhi = tab[((A.x >> 10) & 7u) * 2 + 1];
+        // waits for the group requested at the top of this step, before this step's record stores
+        // are issued: the wait only covers that load and the stores of earlier steps
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(B) : : "memory");
         if (did) {
             // record: the arrow dwords of this step (stored whole; the tail past the row end is
             // overwritten by what follows), then the row's meta dword once the row is done
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     }
     if (live) {
         const int32_t v = (int32_t)(final_word & ~TAGS) - (int32_t)Q * (128 << SH);
-        if (v >= UNREACH) d.status[p] = GBA_PAIR_UNREACHABLE;
+        if (v >= UNREACH || !finished) d.status[p] = GBA_PAIR_UNREACHABLE;
         d.dp_score[p] = v >> SH;
     }
 }
@@ -1469,10 +1472,10 @@ int launch_fill(gba_ctx *c, const Dev &d, uint32_t cls, uint32_t count, hipStrea
     const uint32_t slots = cls_slots((int)cls);
     const bool aff = c->sc.mode == GBA_MODE_AFFINE;
     const size_t rings = aff ? 2 : 1;
-    const size_t lds = (rings * (slots + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
+    const size_t lds = (rings * (slots + PAD_SLOTS) * 64 + LDS_TAB) * 4;
     if (!c->lds_attr_set) {                     // per device, and a ctx lives on one device
-        const size_t mx1 = ((size_t)(cls_slots(LANE_CLS_LINEAR - 1) + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
-        const size_t mx2 = (2 * (size_t)(cls_slots(LANE_CLS_AFFINE - 1) + PAD_SLOTS) * 64 + LDS_TAB + LDS_FIFO) * 4;
+        const size_t mx1 = ((size_t)(cls_slots(LANE_CLS_LINEAR - 1) + PAD_SLOTS) * 64 + LDS_TAB) * 4;
+        const size_t mx2 = (2 * (size_t)(cls_slots(LANE_CLS_AFFINE - 1) + PAD_SLOTS) * 64 + LDS_TAB) * 4;
         const size_t mx = mx1 > mx2 ? mx1 : mx2;
         HIPCHK(c, hipFuncSetAttribute((const void *)k_fill<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_fill<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx));
