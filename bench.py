@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 # HBM bytes of one step's k_fill launches, from separate rocprofv3 --pmc passes of this command at the
 # default workload (profiles/r01_step4_hbm_pmc.txt): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction)
-MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 106496): 32475892 * 1024 + 2 * 4232249 * 1024}
+MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 110592): 38691153 * 1024 + 2 * 4836839 * 1024}
 OPS_PER_CELL = 8            # algorithmic int32 ops per DP cell, linear gaps
 BYTES_PER_CELL = 0.25       # algorithmic traceback bytes per cell (2-bit arrows)
 VALU_PEAK_TOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz int32 lane-ops/s (= half the 157.3 TFLOP/s fp32 vector peak)
@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=106496, help="pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=110592, help="pairs per GPU per step")
     ap.add_argument("--workload", default="c2_10kb_linear")
     ap.add_argument("--band", type=int, default=None, help="override the preset's band")
     ap.add_argument("--max-band", type=int, default=250, help="cap of the widened band in guide gaps (experiments)")
