@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM bytes of one step's k_fill launches, from separate rocprofv3 --pmc passes of this command at the
-# default workload (profiles/r01_step4_hbm_pmc.txt): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction)
+# default workload (profiles/r01_step5_hbm_pmc.txt): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction)
 MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 110592): 38691153 * 1024 + 2 * 4836839 * 1024}
 OPS_PER_CELL = 8            # algorithmic int32 ops per DP cell, linear gaps
 BYTES_PER_CELL = 0.25       # algorithmic traceback bytes per cell (2-bit arrows)
