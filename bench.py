@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=110592, help="pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=122880, help="pairs per GPU per step")
     ap.add_argument("--workload", default="c2_10kb_linear")
     ap.add_argument("--band", type=int, default=None, help="override the preset's band")
     ap.add_argument("--max-band", type=int, default=250, help="cap of the widened band in guide gaps (experiments)")

@@ -49,7 +49,8 @@ constexpr uint32_t MAX_COLS = 1u << 20;
 // (32 << class slots) that holds its widest "shift + width".  Each non-empty class is one launch.
 constexpr int NCLS = 5;                      // lane-per-pair classes of 32, 64, 128, 256 slots, then the wave-per-pair class
 constexpr int CLS_WIDE = NCLS - 1;           // pairs too wide for the lane classes in use: k_fill_wide / k_fill_wide_affine
-constexpr int LANE_CLS_LINEAR = 3;           // linear gaps: lane classes up to 128 slots, anything wider is cheaper wave-per-pair
+constexpr int LANE_CLS_LINEAR = 3;           // linear gaps: lane classes of 32, 64, 128 slots, anything wider is cheaper wave-per-pair
+                                             // (a 96-slot class was measured: the batch gets slower, not faster)
 constexpr int LANE_CLS_AFFINE = 3;           // affine gaps: the same (two rings per wave)
 constexpr int PAD_SLOTS = 3;                 // spare slots behind a ring
 constexpr int SPAN_MARGIN = 4;               // a pair fits a class if its widest shift + width <= slots - SPAN_MARGIN (k_fill touches up to 7 slots past a row end)
@@ -182,10 +183,10 @@ __global__ void k_meta(Dev d, int mode, int kband_k)
     // Every DP row has one ROW word.  Columns enter the band at most T + 1 + sum|drift| times in
     // total (the right edge only moves back when a widened gap ends), eight per EXT word, plus at
     // most one partly filled EXT word per row that needs any (the boundary row, the first row of
-    // a gap, the first row of a block).  Rounded up to whole 4-word groups plus two groups that
+    // a gap, the first row of a block).  Rounded up to whole 64-byte sectors plus one sector that
     // k_fill may prefetch past the end.
     uint64_t wc = (uint64_t)Q + 1 + ((uint64_t)T + 1 + drift_sum) / 8 + 2ull * nb + 4;
-    wc = ((wc + 3) & ~3ull) + 8;
+    wc = ((wc + 15) & ~15ull) + 16;
     d.wcap[p] = st == GBA_PAIR_OK ? (uint32_t)wc : 0;
     d.span[p] = 0; d.ncells[p] = 0; d.lo_last[p] = 0; d.dp_score[p] = 0; d.cls[p] = NCLS; d.recdw[p] = 0;
 }
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
         span = max(span, __shfl_xor(span, o, 64));
     }
     wide = __any(wide) || nw + 8u > wcap;        // the second cannot happen (see k_meta); never overrun the stream
-    // k_fill fetches whole 4-word groups a little past the last word
+    // k_fill fetches whole sectors; what it may pop past the last word is zero
     for (uint32_t x = nw + lane; x < wcap && x < nw + 24u; x += 64) g[x] = 0;
     if (lane == 0) {
         d.span[p] = span; d.ncells[p] = ncells; d.recdw[p] = recdw;
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
 __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
 {
     __shared__ uint64_t sm[17];
-    __shared__ uint32_t cnt[NCLS + 1], base[NCLS + 1];
+    __shared__ uint32_t cnt[NCLS + 1], base[NCLS + 1], cmap[NCLS + 1];
     if (threadIdx.x <= NCLS) cnt[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < d.n; p += blockDim.x) {
@@ -496,6 +497,26 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        // At most two lane classes are launched (with the wave-per-pair class that makes three
+        // concurrent launches, as many as there are hardware queues to run them side by side; a
+        // class queued behind another one adds a whole launch of ~20 ms).  A small widest class
+        // goes wave-per-pair (a lone lane-per-pair wave lasts as long as a full launch); then the
+        // narrowest classes merge upwards until two are left.
+        for (int c = 0; c <= NCLS; c++) cmap[c] = (uint32_t)c;
+        auto nonempty = [&]() { int k = 0; for (int c = 0; c < CLS_WIDE; c++) k += cnt[c] ? 1 : 0; return k; };
+        if (has_wide && nonempty() > 2) {
+            int top = CLS_WIDE - 1;
+            while (!cnt[top]) top--;
+            if (cnt[top] <= 1024u) { cnt[CLS_WIDE] += cnt[top]; cnt[top] = 0; cmap[top] = CLS_WIDE; }
+        }
+        while (nonempty() > 2) {
+            int lo = 0;
+            while (!cnt[lo]) lo++;
+            int up = lo + 1;
+            while (!cnt[up]) up++;
+            cnt[up] += cnt[lo]; cnt[lo] = 0;
+            for (int c = 0; c < CLS_WIDE; c++) if (cmap[c] == (uint32_t)lo) cmap[c] = (uint32_t)up;
+        }
         uint32_t a = 0;
         for (int c = 0; c < NCLS; c++) { base[c] = a; a += cnt[c]; }
         base[NCLS] = a;
@@ -505,21 +526,20 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
     __syncthreads();
     // Four consecutive pairs per thread and packed counters: within one iteration (4096 pairs) one
     // scan carries the counts of the four lane classes (16 bits each), a second one the count of
-    // the wide class (13 bits) with the record dwords above it; totals are carried unpacked.
+    // the wide class; totals are carried unpacked.
     static_assert(NCLS == 5 && CLS_WIDE == 4, "packing of the class counters");
     uint32_t runc[NCLS] = {0, 0, 0, 0, 0};
-    uint64_t carry = 0, cells = 0;
+    uint64_t cells = 0;
     for (uint32_t b0 = 0; b0 < d.n; b0 += 4 * blockDim.x) {
         uint32_t c[4];
-        uint64_t rd[4], la = 0, lb = 0;
+        uint64_t la = 0, lb = 0;
 #pragma unroll
         for (int x = 0; x < 4; x++) {
             const uint32_t p = b0 + 4 * threadIdx.x + x;
-            c[x] = p < d.n ? d.cls[p] : NCLS;
-            rd[x] = c[x] < NCLS ? (uint64_t)d.recdw[p] + 16u : 0;
+            c[x] = p < d.n ? cmap[d.cls[p]] : NCLS;
             if (c[x] < NCLS) cells += d.ncells[p];
             la += c[x] < CLS_WIDE ? 1ull << (16 * c[x]) : 0ull;
-            lb += (c[x] == CLS_WIDE ? 1ull : 0ull) + (rd[x] << 13);
+            lb += c[x] == CLS_WIDE ? 1ull : 0ull;
         }
         uint64_t totA, totB;
         uint64_t ea = block_excl_scan(la, sm, &totA);
@@ -528,15 +548,38 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
         for (int x = 0; x < 4; x++) {
             const uint32_t p = b0 + 4 * threadIdx.x + x;
             if (c[x] < CLS_WIDE) d.order[base[c[x]] + runc[c[x]] + (uint32_t)((ea >> (16 * c[x])) & 0xffffu)] = p;
-            else if (c[x] == CLS_WIDE) d.order[base[CLS_WIDE] + runc[CLS_WIDE] + (uint32_t)(eb & 0x1fffu)] = p;
-            if (p < d.n) d.rec_off[p] = carry + (eb >> 13) + 4u;
+            else if (c[x] == CLS_WIDE) d.order[base[CLS_WIDE] + runc[CLS_WIDE] + (uint32_t)eb] = p;
             ea += c[x] < CLS_WIDE ? 1ull << (16 * c[x]) : 0ull;
-            eb += (c[x] == CLS_WIDE ? 1ull : 0ull) + (rd[x] << 13);
+            eb += c[x] == CLS_WIDE ? 1ull : 0ull;
         }
 #pragma unroll
         for (int k = 0; k < CLS_WIDE; k++) runc[k] += (uint32_t)((totA >> (16 * k)) & 0xffffu);
-        runc[CLS_WIDE] += (uint32_t)(totB & 0x1fffu);
-        carry += totB >> 13;
+        runc[CLS_WIDE] += (uint32_t)totB;
+    }
+    __syncthreads();                             // `order` is complete and visible to the block
+    // Record offsets follow `order`: the records of a class are contiguous and the 64 pairs of a
+    // fill wave are neighbours, so a wave's record region is at most 64 pairs long (k_fill addresses
+    // it with 32-bit byte offsets from the region's start).
+    const uint32_t n_ok = base[NCLS];
+    uint64_t carry = 0;
+    for (uint32_t b0 = 0; b0 < n_ok; b0 += 4 * blockDim.x) {
+        uint32_t q[4];
+        uint64_t rd[4], lr = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const uint32_t i = b0 + 4 * threadIdx.x + x;
+            q[x] = i < n_ok ? d.order[i] : 0xffffffffu;
+            rd[x] = i < n_ok ? (uint64_t)d.recdw[q[x]] + 16u : 0;
+            lr += rd[x];
+        }
+        uint64_t tot;
+        uint64_t er = carry + block_excl_scan(lr, sm, &tot);
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            if (q[x] != 0xffffffffu) d.rec_off[q[x]] = er + 4u;
+            er += rd[x];
+        }
+        carry += tot;
     }
     uint64_t tot;
     block_excl_scan(cells, sm, &tot);
@@ -562,14 +605,21 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
 // of 3 / 8 entering columns), which is why a pair's widest shift + width must stay SPAN_MARGIN
 // below the ring size.
 //
-// Guide words are read in 16-byte groups into registers: group A holds the unread words (A.x is
-// the next one; a pop shifts the group down), group B is the group after it.  When a pop empties
-// A, B takes its place and the lane requests the following group into B.  The request is one
-// inline-asm block at the top level of the loop that narrows EXEC to the requesting lanes itself
-// (inside a C++ branch the compiler gives the load a scratch destination and copies it into B at
-// the end of the branch, before the data has arrived); it is waited for at the end of the step,
-// the only vector-memory wait in the loop, a whole step before B can be needed.  Record dwords
-// are stored directly.  No LDS is spent on the stream: LDS is what limits the waves per CU.
+// Guide words are read a 64-byte sector (16 words) at a time into registers R0..R3; group A holds
+// the unread words of the current 4-word group (A.x is the next one; a pop shifts the group down)
+// and is refilled from R0..R3 in turn.  When A takes the last group of the sector, the lane
+// requests the next sector into R0..R3: four 16-byte loads from one inline-asm block that narrows
+// EXEC to the requesting lanes itself (inside a C++ branch the compiler gives a load a scratch
+// destination and copies it at the end of the branch, before the data has arrived).  The block
+// ends with s_waitcnt vmcnt(4): everything older than the four loads just issued has completed,
+// i.e. a request has a whole step to arrive and is complete three pops before R0 can be needed;
+// it is the only vector-memory wait in the loop.  Nothing between two executions of the block may
+// move R0..R3 to other registers (check the ISA after changing the loop).  A sector is fetched
+// from memory once and used up by its lane; with one
+// 16-byte load per four pops the L2 had to keep a 128-byte line per lane for 32 pops, which it
+// cannot do for 130 k lanes (measured: at two waves per SIMD everywhere the guide loads alone
+// made the launch 45 % longer).  Record dwords are stored directly.  No LDS is spent on the
+// stream: LDS is what limits the waves per CU.
 constexpr int LDS_TAB = 16;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -611,10 +661,10 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     char *recb = (char *)(d.rec + rbase);
     uint32_t rob = (uint32_t)(d.rec_off[p] - rbase) * 4u;
 
-    // stream words: A = unread words of the current group (na of them, A.x next), B = the group
-    // after it, wi = index of the first word not yet requested.  Every stream holds at least 16 words.
-    u32x4 A = *(const u32x4 *)(st), B = *(const u32x4 *)(st + 4);
-    uint32_t na = 4, wi = 8;
+    // stream words: see above.  Streams start 64-byte aligned and are whole sectors long.
+    u32x4 R0 = *(const u32x4 *)(st), R1 = *(const u32x4 *)(st + 4), R2 = *(const u32x4 *)(st + 8), R3 = *(const u32x4 *)(st + 12);
+    u32x4 A = R0;
+    uint32_t na = 4, gi = 1, ws = 16;        // words left in A; group of the sector that refills A next; first word of the next sector
     // No pair needs more steps than stream words plus one step per CAP cells; the loop stops there
     // whatever the stream holds.
     uint32_t max_steps = wcap + (uint32_t)(d.ncells[p] / (uint32_t)CAP) + 16u;
@@ -665,20 +715,27 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
         if (pop_row || pop_ext) {
             A.x = A.y; A.y = A.z; A.z = A.w;
             if (--na == 0u) {
-                A = B; na = 4;
-                req = wi + 4u <= wcap ? 1u : 0u;
+                A = gi == 0u ? R0 : gi == 1u ? R1 : gi == 2u ? R2 : R3;
+                na = 4;
+                gi = (gi + 1u) & 3u;
+                req = gi == 0u && ws + 16u <= wcap ? 1u : 0u;     // R3 has just been taken: the sector is used up
             }
         }
         {
-            const uint32_t *src = st + wi;
+            const uint32_t *src = st + ws;
             uint64_t saved;
             asm volatile("s_mov_b64 %[sv], exec\n\t"
                          "v_cmp_ne_u32_e32 vcc, 0, %[rq]\n\t"
                          "s_and_b64 exec, exec, vcc\n\t"
-                         "global_load_dwordx4 %[b], %[sp], off\n\t"
-                         "s_mov_b64 exec, %[sv]"
-                         : [b] "+v"(B), [sv] "=&s"(saved) : [rq] "v"(req), [sp] "v"(src) : "vcc", "scc", "memory");
-            wi += req * 4u;
+                         "global_load_dwordx4 %[r0], %[sp], off\n\t"
+                         "global_load_dwordx4 %[r1], %[sp], off offset:16\n\t"
+                         "global_load_dwordx4 %[r2], %[sp], off offset:32\n\t"
+                         "global_load_dwordx4 %[r3], %[sp], off offset:48\n\t"
+                         "s_mov_b64 exec, %[sv]\n\t"
+                         "s_waitcnt vmcnt(4)"
+                         : [r0] "+v"(R0), [r1] "+v"(R1), [r2] "+v"(R2), [r3] "+v"(R3), [sv] "=&s"(saved)
+                         : [rq] "v"(req), [sp] "v"(src) : "vcc", "scc", "memory");
+            ws += req * 16u;
         }
         // ---- 2. up to CAP cells of the current row, in groups of 8
         const bool did = !finished && ext_left == 0u && k0 < W;
@@ -758,9 +815,6 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
             }
         }
         nmlo = tab[((A.x >> 10) & 7u) * 2]; nmhi = tab[((A.x >> 10) & 7u) * 2 + 1];
-        // waits for the group requested at the top of this step, before this step's record stores
-        // are issued: the wait only covers that load and the stores of earlier steps
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(B) : : "memory");
         if (did) {
             // record: the arrow dwords of this step (stored whole; the tail past the row end is
             // overwritten by what follows), then the row's meta dword once the row is done
@@ -1063,7 +1117,7 @@ __global__ __launch_bounds__(64) void k_fill_wide_affine(Dev d, FillConst fc)
 // together whenever any lane is about to leave one, one round trip per ~20 rows.
 // Linear records hold 2 bits per cell, affine records one byte per cell (M arrow in bits 3..5,
 // insertion-gap bit 2, deletion-gap bit 1).
-constexpr int TB_RW = 64, TB_TW = 16;
+constexpr int TB_RW = 64, TB_TW = 12;
 #ifndef GBA_TB_LANES
 #define GBA_TB_LANES 64
 #endif
