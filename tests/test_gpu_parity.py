@@ -333,6 +333,38 @@ def test_many_short_pairs(ctx, api, oracle, synth):
         assert np.array_equal(ob[f], blocks[f]), f
 
 
+def test_sparse_class_in_a_large_batch(ctx, api, oracle, synth):
+    """More than 5 GB of traceback records with a class that holds one pair in 680: the 64 pairs of
+    that class's only wave lie across the whole batch, their records must not."""
+    n = 44_000
+    batch = synth.generate(n, read_len=10_000, seed=23, drop_frac=0.0, p_ins=0.03, p_del=0.02, p_sub=0.01)
+    batch = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()}
+    rare = np.arange(137, n, 680)
+    for p in rare:                                   # keep every 60th block: long gaps, rows of 60 to 120 cells
+        bo, nb = int(batch["blk_off"][p]), int(batch["n_blk"][p])
+        keep = np.r_[np.arange(0, nb - 1, 60), nb - 1]
+        batch["blocks"][bo:bo + len(keep)] = batch["blocks"][bo:bo + nb][keep]
+        batch["n_blk"][p] = len(keep)
+    kw = dict()                                      # at these error rates everything else fits the 64-slot class
+    ctx.set_scoring(api.make_scoring(**kw))
+    pairs, blocks, rc = ctx.refine_host(batch)
+    assert rc == 0
+    P = oracle.make_params(**kw)
+    rng = np.random.default_rng(1)
+    for p in np.r_[rare, rng.integers(0, n, 60)]:
+        q, t, b = synth.pair(batch, int(p))
+        o, ob = oracle.align(q, t, b, P)
+        k = pairs[p]
+        assert int(k["status"]) == o["status"], (p, int(k["status"]), o["status"])
+        if o["status"] != 0:
+            continue
+        for f in util.FIELDS:
+            assert int(o[f]) == int(k[f]), (f, p)
+        kb = blocks[int(k["blk_off"]):int(k["blk_off"]) + int(k["n_blk"])]
+        assert np.array_equal(kb, ob), p
+    assert int((pairs["status"] == 0).sum()) >= n - len(rare)
+
+
 def test_full_size_properties(ctx, api, oracle, synth):
     """Benchmark-sized pairs: size-independent invariants on all pairs, oracle parity on a sample."""
     batch, cfg = synth.preset("c2_10kb_linear", 2048)
