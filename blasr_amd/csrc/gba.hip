@@ -611,9 +611,11 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
 // requests the next sector into R0..R3: four 16-byte loads from one inline-asm block that narrows
 // EXEC to the requesting lanes itself (inside a C++ branch the compiler gives a load a scratch
 // destination and copies it at the end of the branch, before the data has arrived).  The block
-// ends with s_waitcnt vmcnt(4): everything older than the four loads just issued has completed,
-// i.e. a request has a whole step to arrive and is complete three pops before R0 can be needed;
-// it is the only vector-memory wait in the loop.  Nothing between two executions of the block may
+// begins with s_waitcnt vmcnt(0): what the previous step requested has arrived (it had a whole
+// step for that) three pops before R0 can be needed, whatever the hardware does with loads whose
+// EXEC is empty and in whatever order memory operations complete; it is the only vector-memory
+// wait in the loop.  (Waiting only for operations older than the last two steps, with requests
+// half a sector earlier, was tried: not faster.)  Nothing between two executions of the block may
 // move R0..R3 to other registers (check the ISA after changing the loop).  A sector is fetched
 // from memory once and used up by its lane; with one
 // 16-byte load per four pops the L2 had to keep a 128-byte line per lane for 32 pops, which it
@@ -724,15 +726,15 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
         {
             const uint32_t *src = st + ws;
             uint64_t saved;
-            asm volatile("s_mov_b64 %[sv], exec\n\t"
+            asm volatile("s_waitcnt vmcnt(0)\n\t"
+                         "s_mov_b64 %[sv], exec\n\t"
                          "v_cmp_ne_u32_e32 vcc, 0, %[rq]\n\t"
                          "s_and_b64 exec, exec, vcc\n\t"
                          "global_load_dwordx4 %[r0], %[sp], off\n\t"
                          "global_load_dwordx4 %[r1], %[sp], off offset:16\n\t"
                          "global_load_dwordx4 %[r2], %[sp], off offset:32\n\t"
                          "global_load_dwordx4 %[r3], %[sp], off offset:48\n\t"
-                         "s_mov_b64 exec, %[sv]\n\t"
-                         "s_waitcnt vmcnt(4)"
+                         "s_mov_b64 exec, %[sv]"
                          : [r0] "+v"(R0), [r1] "+v"(R1), [r2] "+v"(R2), [r3] "+v"(R3), [sv] "=&s"(saved)
                          : [rq] "v"(req), [sp] "v"(src) : "vcc", "scc", "memory");
             ws += req * 16u;
