@@ -830,13 +830,10 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
             if constexpr (!AFF) {
                 // one store per step: a row that ends here appends its meta dword to the arrow dwords
                 // (the dword behind a one-dword row is overwritten by the next store)
-                if (k0 >= W) {
-                    *(u32x3u *)(recb + rob) = u32x3u{ar[0], rem > 16u ? ar[1] : meta, meta};
-                    rob += rem > 16u ? 12u : 8u;
-                } else {
-                    *(u32x2u *)(recb + rob) = u32x2u{ar[0], ar[1]};
-                    rob += 8u;
-                }
+                // (a row that goes on stores a dword too many as well: its next step overwrites it)
+                const bool one = k0 >= W && rem <= 16u;
+                *(u32x3u *)(recb + rob) = u32x3u{ar[0], one ? meta : ar[1], meta};
+                rob += k0 >= W && rem > 16u ? 12u : 8u;
             }
             if (k0 >= W) {
                 if constexpr (AFF) {
