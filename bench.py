@@ -23,8 +23,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM bytes of one step's k_fill launches, from separate rocprofv3 --pmc passes of this command at the
-# default workload (profiles/r01_step6_hbm_pmc.txt): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction)
-MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 122880): 39754830 * 1024 + 2 * 3994765 * 1024}
+# default workload (profiles/r01_step7_hbm_pmc.txt): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction)
+MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 122880): 39974036 * 1024 + 2 * 3988253 * 1024}
 OPS_PER_CELL = 8            # algorithmic int32 ops per DP cell, linear gaps
 BYTES_PER_CELL = 0.25       # algorithmic traceback bytes per cell (2-bit arrows)
 VALU_PEAK_TOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz int32 lane-ops/s (= half the 157.3 TFLOP/s fp32 vector peak)
