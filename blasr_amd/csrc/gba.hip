@@ -847,6 +847,8 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
             }
         }
     }
+    // the last step may have requested a sector: nothing may reuse R0..R3's registers before it has arrived
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(R0), "+v"(R1), "+v"(R2), "+v"(R3) : : "memory");
     if (live) {
         const int32_t v = (int32_t)(final_word & ~TAGS) - (int32_t)Q * (128 << SH);
         if (v >= UNREACH || !finished) d.status[p] = GBA_PAIR_UNREACHABLE;
@@ -1400,10 +1402,12 @@ __global__ void k_results_init(Dev d, gba_pair_result *res)
 // n_blk -> offsets into the caller's block arena (single block).  The block counts come from
 // d.span (free after k_plan: k_results_init zeroes it, the tracebacks store the counts there), the
 // offsets go to d.word_off (free after the fill kernels).
+// *needed holds the blocks of the parts of the batch scanned before this one and receives the sum.
 __global__ __launch_bounds__(1024) void k_scan1(Dev d, uint64_t *needed)
 {
     __shared__ uint64_t sm[17];
-    uint64_t carry = 0;
+    uint64_t carry = *needed;
+    __syncthreads();
     // four consecutive pairs per thread
     for (uint32_t b0 = 0; b0 < d.n; b0 += 4 * blockDim.x) {
         uint64_t v[4], lv = 0;
@@ -1460,8 +1464,8 @@ struct Buf {
 
 }  // namespace
 
-constexpr int NSLOT = 2;      // a batch can be run as two half batches, staggered, so that one half's guide
-                              // construction and traceback run under the other half's DP fill
+constexpr int NSLOT = 2;      // a large batch is run in parts that alternate between two slots, staggered, so that one
+                              // part's guide construction and traceback run under the other part's DP fill
 constexpr int NAUXS = 2;      // auxiliary streams per slot (wider classes run beside the bulk class)
 
 // Everything one (half) batch in flight needs of its own.
@@ -1469,7 +1473,7 @@ struct Slot {
     Buf b_plan, b_guide, b_tc, b_rec, b_blk;     // device scratch (grow-only)
     Plan *h_plan = nullptr;                      // pinned
     hipStream_t s = nullptr, aux[NAUXS] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[NAUXS] = {}, ev_done = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join[NAUXS] = {}, ev_done = nullptr, ev_scan = nullptr;
     hipEvent_t t_fill0 = nullptr, t_fill1 = nullptr, t_tb1 = nullptr;
     Plan pl;                                     // host copy of the half batch's plan
     uint64_t rows = 0;
@@ -1487,9 +1491,10 @@ struct gba_ctx {
     gba_scoring sc;
     FillConst fc;
     TbConst tbc;
-    uint32_t split_min = 0xffffffffu; // batches of at least this many pairs are run as two staggered halves (env GBA_SPLIT_MIN).
-                                     // Off by default: on MI355X the halves compete for the same SIMD issue slots and LDS
-                                     // (46.2 ms unsplit, 45.9 ms split with 8 hardware queues, 65 ms with the default 4)
+    uint32_t part_pairs = 122880;    // a batch of more than ~1.07 x this many pairs is run in staggered parts of about this
+                                     // size (env GBA_PART_PAIRS, 0 = never).  Two lane-per-pair waves per SIMD is what the GPU
+                                     // can use (1920 waves here); measured on 10-kb pairs: 245 760 pairs in one piece 658 GCUPS,
+                                     // in two staggered parts 734, a single batch of 122 880 pairs 714
     // device scratch (grow-only)
     Buf b_ref;                       // reference for batches without a target arena (gba_set_reference)
     uint64_t ref_len = 0;
@@ -1671,10 +1676,30 @@ bool batch_complete(const gba_batch *b)
     return b->n_pairs == 0 || (b->q_arena && b->blocks && b->q_off && b->t_off && b->blk_off && b->q_len && b->t_len && b->n_blk);
 }
 
-// Runs one batch whose inputs and outputs are device pointers.  With GBA_SPLIT_MIN set, a batch of
-// at least that many pairs is run as two half batches: the second half's target packing and guide construction are enqueued once the first
-// half's fills are under way, and the first half's traceback runs under the second half's fill.
-// The host waits twice per half (arena sizes, launch grids) and once at the end.
+// What the timing of a batch is made of, folded in part by part.
+struct TimeAcc {
+    float f0 = 1e30f, f1 = 0, tb1 = 0;
+    uint32_t launches = 0;
+    uint64_t cells = 0, rows = 0, rec = 0;
+};
+
+// The part that ran last in `sl` has completed: add its events and counts.
+int fold_timing(gba_ctx *c, Slot &sl, TimeAcc &a)
+{
+    float x, e, t;
+    HIPCHK(c, hipEventElapsedTime(&x, c->ev[0], sl.t_fill0));
+    HIPCHK(c, hipEventElapsedTime(&e, c->ev[0], sl.t_fill1));
+    HIPCHK(c, hipEventElapsedTime(&t, c->ev[0], sl.t_tb1));
+    a.f0 = x < a.f0 ? x : a.f0; a.f1 = e > a.f1 ? e : a.f1; a.tb1 = t > a.tb1 ? t : a.tb1;
+    a.launches += sl.launches; a.cells += sl.pl.total_cells; a.rows += sl.rows; a.rec += sl.pl.total_rec_dwords * 4;
+    return GBA_OK;
+}
+
+// Runs one batch whose inputs and outputs are device pointers.  A batch much larger than
+// gba_ctx::part_pairs is run in parts of about that size which alternate between the two slots:
+// a part's target packing and guide construction are enqueued while the part before it fills, and
+// its traceback and block copy run under the fill of the part after it; a slot's scratch is reused
+// by every second part.  The host waits twice per part (arena sizes, launch grids) and once at the end.
 int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
 {
     const uint32_t n = b->n_pairs;
@@ -1710,50 +1735,56 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     g.rec_off = (uint64_t *)c->b_pair64[2].ptr; g.ncells = (uint64_t *)c->b_pair64[3].ptr;
     g.word_off = (uint64_t *)c->b_pair64[4].ptr;
     const bool timing = (c->flags & GBA_FLAG_TIMING) != 0;
-    uint32_t p0[NSLOT + 1] = {0, n, n};
-    if (n >= c->split_min) p0[1] = (n / 2 + 63) & ~63u;   // whole waves in the first half
-    const int ns = p0[1] < n ? NSLOT : 1;
-    Dev d[NSLOT];
-    for (int h = 0; h < ns; h++) d[h] = sub_dev(g, p0[h], p0[h + 1] - p0[h], c->slot[h]);
+    uint32_t parts = 1;
+    if (c->part_pairs && n > c->part_pairs + c->part_pairs / 15) {
+        parts = (uint32_t)(((uint64_t)n + c->part_pairs / 2) / c->part_pairs);
+        if (parts < 2) parts = 2;
+    }
+    const uint32_t per = (uint32_t)((((uint64_t)n + parts - 1) / parts + 63) & ~63ull);     // whole waves
+    parts = (n + per - 1) / per;
     gba_pair_result *res = out->pairs;
+    uint64_t *needed = (uint64_t *)c->b_needed.ptr;
     hipStream_t s = c->slot[0].s;
+    TimeAcc acc;
+    bool used[NSLOT] = {};
 
     if (timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    if (ns == 2) {                                     // the second slot's stream starts after the batch's inputs are ready
+    HIPCHK(c, hipMemsetAsync(needed, 0, 8, s));
+    if (parts > 1) {                                   // the second slot's stream starts after the batch's inputs are ready
         HIPCHK(c, hipEventRecord(c->slot[0].ev_fork, s));
         HIPCHK(c, hipStreamWaitEvent(c->slot[1].s, c->slot[0].ev_fork, 0));
     }
-    for (int h = 0; h < ns; h++) { int rc = phase_sizes(c, c->slot[h], d[h]); if (rc) return rc; }
-    for (int h = 0; h < ns; h++) {
-        int rc = phase_guide(c, c->slot[h], d[h]); if (rc) return rc;
-        rc = phase_fill(c, c->slot[h], d[h], res + p0[h], (uint32_t)NAUXS); if (rc) return rc;
+    for (uint32_t h = 0; h < parts; h++) {
+        Slot &sl = c->slot[h % NSLOT];
+        const uint32_t first = h * per, cnt = n - first < per ? n - first : per;
+        Dev d = sub_dev(g, first, cnt, sl);
+        int rc = phase_sizes(c, sl, d); if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(sl.s));         // the sizes are here, and the slot's previous part has completed
+        if (timing && used[h % NSLOT]) { rc = fold_timing(c, sl, acc); if (rc) return rc; }
+        used[h % NSLOT] = true;
+        rc = phase_guide(c, sl, d); if (rc) return rc;
+        rc = phase_fill(c, sl, d, res + first, (uint32_t)NAUXS); if (rc) return rc;
+        // block offsets continue where the part before stopped
+        if (h > 0) HIPCHK(c, hipStreamWaitEvent(sl.s, c->slot[(h - 1) % NSLOT].ev_scan, 0));
+        hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, sl.s, d, needed);
+        HIPCHK(c, hipEventRecord(sl.ev_scan, sl.s));
+        hipLaunchKernelGGL(k_emit, dim3(d.n), dim3(256), 0, sl.s, d, res + first, out->blocks, out->blocks_capacity);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(sl.ev_done, sl.s));
     }
-    if (ns == 2) HIPCHK(c, hipStreamWaitEvent(s, c->slot[1].ev_done, 0));
-    hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, s, g, (uint64_t *)c->b_needed.ptr);
-    for (int h = 0; h < ns; h++)
-        hipLaunchKernelGGL(k_emit, dim3(d[h].n), dim3(256), 0, s, d[h], res + p0[h], out->blocks, out->blocks_capacity);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_needed, c->b_needed.ptr, 8, hipMemcpyDeviceToHost, s));
+    if (parts > 1) HIPCHK(c, hipStreamWaitEvent(s, c->slot[1].ev_done, 0));
+    HIPCHK(c, hipMemcpyAsync(c->h_needed, needed, 8, hipMemcpyDeviceToHost, s));
     if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     HIPCHK(c, hipStreamSynchronize(s));
     out->blocks_needed = *c->h_needed;
     if (timing) {
-        // fill: from the first bulk fill's start to the last bulk fill's end (the halves overlap);
+        // fill: from the first bulk fill's start to the last bulk fill's end (parts overlap);
         // traceback: from there to the end of the last traceback
+        for (int x = 0; x < NSLOT; x++)
+            if (used[x]) { int rc = fold_timing(c, c->slot[x], acc); if (rc) return rc; }
         gba_timing &t = c->timing;
-        float f0 = 1e30f, f1 = 0, tb1 = 0;
-        t.fill_launches = 0; t.cells = 0; t.rows = 0; t.record_bytes = 0;
-        for (int h = 0; h < ns; h++) {
-            Slot &sl = c->slot[h];
-            float a, e, x;
-            HIPCHK(c, hipEventElapsedTime(&a, c->ev[0], sl.t_fill0));
-            HIPCHK(c, hipEventElapsedTime(&e, c->ev[0], sl.t_fill1));
-            HIPCHK(c, hipEventElapsedTime(&x, c->ev[0], sl.t_tb1));
-            f0 = a < f0 ? a : f0; f1 = e > f1 ? e : f1; tb1 = x > tb1 ? x : tb1;
-            t.fill_launches += sl.launches; t.cells += sl.pl.total_cells; t.rows += sl.rows;
-            t.record_bytes += sl.pl.total_rec_dwords * 4;
-        }
-        t.fill_ms = f1 - f0; t.traceback_ms = tb1 > f1 ? tb1 - f1 : 0;
+        t.fill_launches = acc.launches; t.cells = acc.cells; t.rows = acc.rows; t.record_bytes = acc.rec;
+        t.fill_ms = acc.f1 - acc.f0; t.traceback_ms = acc.tb1 > acc.f1 ? acc.tb1 - acc.f1 : 0;
         HIPCHK(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[1]));
     }
     return out->blocks_needed > out->blocks_capacity ? GBA_E_NOSPACE : GBA_OK;
@@ -1803,13 +1834,13 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
         if (hipHostMalloc((void **)&c->h_needed, 8) != hipSuccess) { rc = GBA_E_NOMEM; break; }
         for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rc = GBA_E_HIP; break; }
         if (rc) break;
-        if (const char *e = getenv("GBA_SPLIT_MIN")) c->split_min = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char *e = getenv("GBA_PART_PAIRS")) c->part_pairs = (uint32_t)strtoul(e, nullptr, 10);
         for (int h = 0; h < NSLOT && !rc; h++) {
             Slot &sl = c->slot[h];
             if (h == 0) sl.s = c->stream;
             else if (hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking) != hipSuccess) { rc = GBA_E_HIP; break; }
             if (hipHostMalloc((void **)&sl.h_plan, sizeof(Plan)) != hipSuccess) { rc = GBA_E_NOMEM; break; }
-            hipEvent_t *plain[] = {&sl.ev_fork, &sl.ev_done, &sl.ev_join[0], &sl.ev_join[1]};
+            hipEvent_t *plain[] = {&sl.ev_fork, &sl.ev_done, &sl.ev_scan, &sl.ev_join[0], &sl.ev_join[1]};
             for (hipEvent_t *e : plain) if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) rc = GBA_E_HIP;
             hipEvent_t *timed[] = {&sl.t_fill0, &sl.t_fill1, &sl.t_tb1};
             for (hipEvent_t *e : timed) if (hipEventCreate(e) != hipSuccess) rc = GBA_E_HIP;
@@ -1842,7 +1873,7 @@ void gba_destroy(gba_ctx *c)
         Buf *sb[] = {&sl.b_plan, &sl.b_guide, &sl.b_tc, &sl.b_rec, &sl.b_blk};
         for (Buf *b : sb) release(*b);
         if (sl.h_plan) (void)hipHostFree(sl.h_plan);
-        hipEvent_t evs[] = {sl.ev_fork, sl.ev_done, sl.ev_join[0], sl.ev_join[1], sl.t_fill0, sl.t_fill1, sl.t_tb1};
+        hipEvent_t evs[] = {sl.ev_fork, sl.ev_done, sl.ev_scan, sl.ev_join[0], sl.ev_join[1], sl.t_fill0, sl.t_fill1, sl.t_tb1};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

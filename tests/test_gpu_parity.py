@@ -456,14 +456,27 @@ def test_reference_windows_and_reverse_complement(ctx, api, oracle, synth):
         ctx.refine_host(wb)          # no reference, no arena: call out of sequence
 
 
-def test_split_batches(api, oracle, synth, monkeypatch):
-    """GBA_SPLIT_MIN: a batch run as two staggered half batches gives the same results."""
-    monkeypatch.setenv("GBA_SPLIT_MIN", "64")
+@pytest.mark.parametrize("part", ["64", "128", "320"])
+def test_batches_in_parts(api, oracle, synth, monkeypatch, part):
+    """GBA_PART_PAIRS: a batch run as 6, 3 or 2 staggered parts over the two slots gives the same
+    results and the same packed block arena as in one piece (a small arena included)."""
+    monkeypatch.setenv("GBA_PART_PAIRS", part)
     c2 = api.Context(0)
     try:
         batch = synth.generate(333, read_len=1200, len_jitter=900, p_ins=0.1, p_del=0.07, seed=88, decoy_every=7)
         for kw in (dict(), dict(band=60), dict(mode=1, band=16)):
             _run(c2, api, oracle, batch, **kw)
+        c2.set_scoring(api.make_scoring())
+        full, fblocks, rc = c2.refine_host(batch)
+        assert rc == 0
+        small, sblocks, rc = c2.refine_host(batch, blocks_capacity=len(fblocks) // 2)
+        assert rc == -4 and c2.blocks_needed == len(fblocks)
+        fits = full["blk_off"].astype(np.int64) + full["n_blk"] <= len(fblocks) // 2
+        ok = full["status"] == 0
+        assert (small["status"][ok & ~fits] == 4).all() and (small["status"][ok & fits] == 0).all()
+        assert np.array_equal(small["blk_off"], full["blk_off"])
+        end = int((full["blk_off"].astype(np.int64) + full["n_blk"])[ok & fits].max())
+        assert np.array_equal(sblocks[:end], fblocks[:end])
     finally:
         c2.close()
 
