@@ -23,8 +23,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM bytes of one step's k_fill launches, from separate rocprofv3 --pmc passes of this command at the
-# default workload (profiles/r01_step7_hbm_pmc.txt): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction)
-MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 122880): 39974036 * 1024 + 2 * 3988253 * 1024}
+# default workload (profiles/r01_step8_hbm_pmc.txt): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction)
+MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 491520): 162394798 * 1024 + 2 * 15918231 * 1024}
 OPS_PER_CELL = 8            # algorithmic int32 ops per DP cell, linear gaps
 BYTES_PER_CELL = 0.25       # algorithmic traceback bytes per cell (2-bit arrows)
 VALU_PEAK_TOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz int32 lane-ops/s (= half the 157.3 TFLOP/s fp32 vector peak)
@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=122880, help="pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=491520, help="pairs per GPU per step")
     ap.add_argument("--workload", default="c2_10kb_linear")
     ap.add_argument("--band", type=int, default=None, help="override the preset's band")
     ap.add_argument("--max-band", type=int, default=250, help="cap of the widened band in guide gaps (experiments)")
@@ -189,7 +189,7 @@ def main():
             "bound": "valu-int32", "kernel": "k_fill<%s>" % ("true" if affine else "false"),
             "achieved": round(cells_step * ops_cell / fill_s / 1e12, 3), "peak": VALU_PEAK_TOPS,
             "unit": "Tops/s", "frac": round(cells_step * ops_cell / fill_s / 1e12 / VALU_PEAK_TOPS, 4),
-            "ops_per_cell": ops_cell, "fill_ms": round(fill_s * 1e3, 3),
+            "ops_per_cell": ops_cell, "fill_ms": round(fill_s * 1e3, 3),     # bulk fill launches of a step, summed (HIP events)
             "fill_gcups": round(cells_step / fill_s / 1e9, 2),
             "traffic": traffic,
         },

@@ -1678,7 +1678,7 @@ bool batch_complete(const gba_batch *b)
 
 // What the timing of a batch is made of, folded in part by part.
 struct TimeAcc {
-    float f0 = 1e30f, f1 = 0, tb1 = 0;
+    float f0 = 1e30f, f1 = 0, tb1 = 0, fill_sum = 0;
     uint32_t launches = 0;
     uint64_t cells = 0, rows = 0, rec = 0;
 };
@@ -1691,6 +1691,7 @@ int fold_timing(gba_ctx *c, Slot &sl, TimeAcc &a)
     HIPCHK(c, hipEventElapsedTime(&e, c->ev[0], sl.t_fill1));
     HIPCHK(c, hipEventElapsedTime(&t, c->ev[0], sl.t_tb1));
     a.f0 = x < a.f0 ? x : a.f0; a.f1 = e > a.f1 ? e : a.f1; a.tb1 = t > a.tb1 ? t : a.tb1;
+    a.fill_sum += e - x;
     a.launches += sl.launches; a.cells += sl.pl.total_cells; a.rows += sl.rows; a.rec += sl.pl.total_rec_dwords * 4;
     return GBA_OK;
 }
@@ -1778,13 +1779,13 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     HIPCHK(c, hipStreamSynchronize(s));
     out->blocks_needed = *c->h_needed;
     if (timing) {
-        // fill: from the first bulk fill's start to the last bulk fill's end (parts overlap);
-        // traceback: from there to the end of the last traceback
+        // fill: the bulk fill launches of the parts, one after the other (what else runs on the GPU
+        // during a launch makes it longer); traceback: from the last fill's end to the last traceback's
         for (int x = 0; x < NSLOT; x++)
             if (used[x]) { int rc = fold_timing(c, c->slot[x], acc); if (rc) return rc; }
         gba_timing &t = c->timing;
         t.fill_launches = acc.launches; t.cells = acc.cells; t.rows = acc.rows; t.record_bytes = acc.rec;
-        t.fill_ms = acc.f1 - acc.f0; t.traceback_ms = acc.tb1 > acc.f1 ? acc.tb1 - acc.f1 : 0;
+        t.fill_ms = acc.fill_sum; t.traceback_ms = acc.tb1 > acc.f1 ? acc.tb1 - acc.f1 : 0;
         HIPCHK(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[1]));
     }
     return out->blocks_needed > out->blocks_capacity ? GBA_E_NOSPACE : GBA_OK;

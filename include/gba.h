@@ -151,9 +151,9 @@ typedef struct {
 
 /* live measurements of the last waited batch (GBA_FLAG_TIMING) */
 typedef struct {
-    float fill_ms;              /* DP-fill launches on the ctx stream (HIP events): the narrowest classes, i.e. the
-                                   bulk of a batch; up to two wider classes run beside them on other streams */
-    float traceback_ms;         /* traceback launches on the ctx stream, same convention */
+    float fill_ms;              /* bulk DP-fill launches (HIP events around them on their stream), summed over the parts a
+                                   large batch is run in; up to two more classes run beside each on other streams */
+    float traceback_ms;         /* from the end of the last bulk fill to the end of the last traceback */
     float total_ms;             /* first kernel to last kernel of the batch */
     uint32_t fill_launches;
     uint64_t cells;             /* sum of ncells over pairs with status OK */
