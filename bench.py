@@ -167,7 +167,12 @@ def main():
         tm = ctxs[i].timing()
         cells_step += int(tm["cells"])
         rec_bytes += int(tm["record_bytes"])
-    total_cells = cells_step * args.steps * world
+    cells_all, ok_all = cells_step, n_ok
+    if world > 1:        # every rank has its own reads: sum the real counts
+        t = torch.tensor([cells_step, n_ok], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        cells_all, ok_all = int(t[0].item()), int(t[1].item())
+    total_cells = cells_all * args.steps
     gcups = total_cells / dt / 1e9
     fill_s = fill_ms / 1e3 / args.steps
     ops_cell, bytes_cell = (18, 0.75) if affine else (OPS_PER_CELL, BYTES_PER_CELL)   # algorithmic work per cell
@@ -182,7 +187,7 @@ def main():
         "config": {"workload": args.workload, "pairs_per_gpu": n, "read_len": cfg["read_len"],
                    "error": "ins %.2f / del %.2f / sub %.2f" % (cfg["p_ins"], cfg["p_del"], cfg["p_sub"]),
                    "streams": S, "band": cfg["band"], "gaps": cfg["mode"], "reference_len": cfg["ref_len"],
-                   "cells_per_step_per_gpu": cells_step, "pairs_ok": n_ok,
+                   "cells_per_step_per_gpu": cells_step, "pairs_ok": ok_all, "pairs_total": n * world,
                    "parallelism": "reads sharded by index, %d rank(s), no collective" % world},
         "aligned_reads_per_sec": round(n * args.steps * world / dt, 1),
         "roofline": {
