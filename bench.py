@@ -87,11 +87,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        # GBA_BENCH_BACKEND=gloo: rehearsal of the multi-rank path with several ranks on one GPU
+        backend = os.environ.get("GBA_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the alignment path has no CPU fallback")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
+    red = dev if world == 1 or dist.get_backend() == "nccl" else "cpu"      # where the timing reductions live
 
     cfg = dict(synth.PRESETS[args.workload])
     # shard by read index: rank r owns the reads with global index = r (mod world); each rank
@@ -153,7 +157,7 @@ def main():
     fill_ms = sum(a[0] for a in accs) / S
     tb_ms = sum(a[1] for a in accs) / S
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -169,7 +173,7 @@ def main():
         rec_bytes += int(tm["record_bytes"])
     cells_all, ok_all = cells_step, n_ok
     if world > 1:        # every rank has its own reads: sum the real counts
-        t = torch.tensor([cells_step, n_ok], dtype=torch.int64, device=dev)
+        t = torch.tensor([cells_step, n_ok], dtype=torch.int64, device=red)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         cells_all, ok_all = int(t[0].item()), int(t[1].item())
     total_cells = cells_all * args.steps
