@@ -450,8 +450,12 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
             if (off < wcap) g[off] = word;
             uint32_t o = off + 1u;
             for (uint32_t j = 3; j < nnew; j += 8, o++) {
-                uint32_t ew = 0;
-                for (uint32_t x = 0; x < 8 && j + x < nnew; x++) ew |= (uint32_t)tc[cnew + j + x] << (3 * x);
+                // eight codes (bytes below 8) to 3 bits each; the code array has spare bytes behind its end
+                auto pack4 = [](uint32_t v) { return (v & 7u) | ((v >> 5) & 0x38u) | ((v >> 10) & 0x1c0u) | ((v >> 15) & 0xe00u); };
+                const uint32_t lo4 = *(const u32u1 *)(tc + cnew + j), hi4 = *(const u32u1 *)(tc + cnew + j + 4);
+                uint32_t ew = pack4(lo4) | (pack4(hi4) << 12);
+                const uint32_t left = nnew - j;
+                if (left < 8u) ew &= (1u << (3u * left)) - 1u;
                 if (o < wcap) g[o] = ew;
             }
             if (r == Q) d.lo_last[p] = lo;
