@@ -191,7 +191,13 @@ __global__ void k_meta(Dev d, int mode, int kband_k)
     d.span[p] = 0; d.ncells[p] = 0; d.lo_last[p] = 0; d.dp_score[p] = 0; d.cls[p] = NCLS; d.recdw[p] = 0;
 }
 
-// ---------------------------------------------------------------- block-wide scan helpers (1024 threads)
+// ---------------------------------------------------------------- block-wide scan helpers
+// The single-block kernels (k_scan3, k_plan, k_scan1) run SCAN_T threads with SCAN_E consecutive
+// pairs per thread, one wave per SIMD and well under 112 VGPRs: that is what is left on a SIMD
+// that holds two k_fill waves of another part of the batch.  (As 1024-thread blocks they needed a
+// CU with at most one fill wave on every SIMD and waited ~18 ms for one whenever a fill launch had
+// just filled the GPU.)
+constexpr int SCAN_T = 256, SCAN_E = 16, PLAN_E = 8;     // k_plan keeps more per pair in registers
 __device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v)
 {
     const int lane = threadIdx.x & 63;
@@ -222,34 +228,40 @@ __device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t *sm, ui
     return sm[w] + inc - v;
 }
 
+// exclusive scan of in[0..n) into out[0..n) by one block; returns the total
+__device__ __forceinline__ uint64_t scan_array(const uint32_t *in, uint64_t *out, uint32_t n, uint64_t *sm)
+{
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < n; base += SCAN_E * blockDim.x) {
+        uint32_t v[SCAN_E];
+        uint64_t lv = 0;
+#pragma unroll
+        for (int x = 0; x < SCAN_E; x++) {
+            const uint32_t p = base + SCAN_E * threadIdx.x + x;
+            v[x] = p < n ? in[p] : 0u;
+            lv += v[x];
+        }
+        uint64_t tot;
+        uint64_t e = carry + block_excl_scan(lv, sm, &tot);
+#pragma unroll
+        for (int x = 0; x < SCAN_E; x++) {
+            const uint32_t p = base + SCAN_E * threadIdx.x + x;
+            if (p < n) out[p] = e;
+            e += v[x];
+        }
+        carry += tot;
+    }
+    return carry;
+}
+
 // rows -> row_off, cols -> col_off, wcap -> word_off (single block)
-__global__ __launch_bounds__(1024) void k_scan3(Dev d)
+__global__ __launch_bounds__(SCAN_T) void k_scan3(Dev d)
 {
     __shared__ uint64_t sm[17];
-    uint64_t carry_r = 0, carry_c = 0, carry_w = 0;
-    // four consecutive pairs per thread
-    for (uint32_t base = 0; base < d.n; base += 4 * blockDim.x) {
-        uint64_t r[4], c[4], w[4], lr = 0, lc = 0, lw = 0;
-#pragma unroll
-        for (int x = 0; x < 4; x++) {
-            const uint32_t p = base + 4 * threadIdx.x + x;
-            const bool in = p < d.n;
-            r[x] = in ? d.rows[p] : 0; c[x] = in ? d.cols[p] : 0; w[x] = in ? d.wcap[p] : 0;
-            lr += r[x]; lc += c[x]; lw += w[x];
-        }
-        uint64_t tr, tc, tw;
-        uint64_t er = carry_r + block_excl_scan(lr, sm, &tr);
-        uint64_t ec = carry_c + block_excl_scan(lc, sm, &tc);
-        uint64_t ew = carry_w + block_excl_scan(lw, sm, &tw);
-#pragma unroll
-        for (int x = 0; x < 4; x++) {
-            const uint32_t p = base + 4 * threadIdx.x + x;
-            if (p < d.n) { d.row_off[p] = er; d.col_off[p] = ec; d.word_off[p] = ew; }
-            er += r[x]; ec += c[x]; ew += w[x];
-        }
-        carry_r += tr; carry_c += tc; carry_w += tw;
-    }
-    if (threadIdx.x == 0) { d.plan->total_rows = carry_r; d.plan->total_cols = carry_c; d.plan->total_words = carry_w; }
+    const uint64_t tr = scan_array(d.rows, d.row_off, d.n, sm);
+    const uint64_t tc = scan_array(d.cols, d.col_off, d.n, sm);
+    const uint64_t tw = scan_array(d.wcap, d.word_off, d.n, sm);
+    if (threadIdx.x == 0) { d.plan->total_rows = tr; d.plan->total_cols = tc; d.plan->total_words = tw; }
 }
 
 // ---------------------------------------------------------------- k_pack
@@ -482,7 +494,7 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
 // `order` lists the OK pairs grouped by class (stable); rec_off is each pair's record offset in
 // dwords (4 spare dwords precede every pair: the traceback reads 16-byte windows ending at a row;
 // 12 follow it: the fill kernel stores whole steps and lets the next store overwrite the tail).  Pairs whose widest row needs more than the largest class are TOO_WIDE.
-__global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
+__global__ __launch_bounds__(SCAN_T) void k_plan(Dev d, int ncls, int has_wide)
 {
     __shared__ uint64_t sm[17];
     __shared__ uint32_t cnt[NCLS + 1], base[NCLS + 1], cmap[NCLS + 1];
@@ -528,18 +540,18 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
         d.plan->n_ok = a;
     }
     __syncthreads();
-    // Four consecutive pairs per thread and packed counters: within one iteration (4096 pairs) one
+    // PLAN_E consecutive pairs per thread and packed counters: within one iteration (4096 pairs) one
     // scan carries the counts of the four lane classes (16 bits each), a second one the count of
     // the wide class; totals are carried unpacked.
-    static_assert(NCLS == 5 && CLS_WIDE == 4, "packing of the class counters");
+    static_assert(NCLS == 5 && CLS_WIDE == 4 && SCAN_T * PLAN_E < 65536, "packing of the class counters");
     uint32_t runc[NCLS] = {0, 0, 0, 0, 0};
     uint64_t cells = 0;
-    for (uint32_t b0 = 0; b0 < d.n; b0 += 4 * blockDim.x) {
-        uint32_t c[4];
+    for (uint32_t b0 = 0; b0 < d.n; b0 += PLAN_E * blockDim.x) {
+        uint32_t c[PLAN_E];
         uint64_t la = 0, lb = 0;
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
-            const uint32_t p = b0 + 4 * threadIdx.x + x;
+        for (int x = 0; x < PLAN_E; x++) {
+            const uint32_t p = b0 + PLAN_E * threadIdx.x + x;
             c[x] = p < d.n ? cmap[d.cls[p]] : NCLS;
             if (c[x] < NCLS) cells += d.ncells[p];
             la += c[x] < CLS_WIDE ? 1ull << (16 * c[x]) : 0ull;
@@ -549,8 +561,8 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
         uint64_t ea = block_excl_scan(la, sm, &totA);
         uint64_t eb = block_excl_scan(lb, sm, &totB);
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
-            const uint32_t p = b0 + 4 * threadIdx.x + x;
+        for (int x = 0; x < PLAN_E; x++) {
+            const uint32_t p = b0 + PLAN_E * threadIdx.x + x;
             if (c[x] < CLS_WIDE) d.order[base[c[x]] + runc[c[x]] + (uint32_t)((ea >> (16 * c[x])) & 0xffffu)] = p;
             else if (c[x] == CLS_WIDE) d.order[base[CLS_WIDE] + runc[CLS_WIDE] + (uint32_t)eb] = p;
             ea += c[x] < CLS_WIDE ? 1ull << (16 * c[x]) : 0ull;
@@ -566,20 +578,20 @@ __global__ __launch_bounds__(1024) void k_plan(Dev d, int ncls, int has_wide)
     // it with 32-bit byte offsets from the region's start).
     const uint32_t n_ok = base[NCLS];
     uint64_t carry = 0;
-    for (uint32_t b0 = 0; b0 < n_ok; b0 += 4 * blockDim.x) {
-        uint32_t q[4];
-        uint64_t rd[4], lr = 0;
+    for (uint32_t b0 = 0; b0 < n_ok; b0 += PLAN_E * blockDim.x) {
+        uint32_t q[PLAN_E], rd[PLAN_E];
+        uint64_t lr = 0;
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
-            const uint32_t i = b0 + 4 * threadIdx.x + x;
+        for (int x = 0; x < PLAN_E; x++) {
+            const uint32_t i = b0 + PLAN_E * threadIdx.x + x;
             q[x] = i < n_ok ? d.order[i] : 0xffffffffu;
-            rd[x] = i < n_ok ? (uint64_t)d.recdw[q[x]] + 16u : 0;
+            rd[x] = i < n_ok ? d.recdw[q[x]] + 16u : 0u;
             lr += rd[x];
         }
         uint64_t tot;
         uint64_t er = carry + block_excl_scan(lr, sm, &tot);
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
+        for (int x = 0; x < PLAN_E; x++) {
             if (q[x] != 0xffffffffu) d.rec_off[q[x]] = er + 4u;
             er += rd[x];
         }
@@ -1407,25 +1419,25 @@ __global__ void k_results_init(Dev d, gba_pair_result *res)
 // d.span (free after k_plan: k_results_init zeroes it, the tracebacks store the counts there), the
 // offsets go to d.word_off (free after the fill kernels).
 // *needed holds the blocks of the parts of the batch scanned before this one and receives the sum.
-__global__ __launch_bounds__(1024) void k_scan1(Dev d, uint64_t *needed)
+__global__ __launch_bounds__(SCAN_T) void k_scan1(Dev d, uint64_t *needed)
 {
     __shared__ uint64_t sm[17];
     uint64_t carry = *needed;
     __syncthreads();
-    // four consecutive pairs per thread
-    for (uint32_t b0 = 0; b0 < d.n; b0 += 4 * blockDim.x) {
-        uint64_t v[4], lv = 0;
+    for (uint32_t b0 = 0; b0 < d.n; b0 += SCAN_E * blockDim.x) {
+        uint32_t v[SCAN_E];
+        uint64_t lv = 0;
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
-            const uint32_t p = b0 + 4 * threadIdx.x + x;
-            v[x] = p < d.n && d.status[p] == GBA_PAIR_OK ? d.span[p] : 0;
+        for (int x = 0; x < SCAN_E; x++) {
+            const uint32_t p = b0 + SCAN_E * threadIdx.x + x;
+            v[x] = p < d.n && d.status[p] == GBA_PAIR_OK ? d.span[p] : 0u;
             lv += v[x];
         }
         uint64_t tot;
         uint64_t e = carry + block_excl_scan(lv, sm, &tot);
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
-            const uint32_t p = b0 + 4 * threadIdx.x + x;
+        for (int x = 0; x < SCAN_E; x++) {
+            const uint32_t p = b0 + SCAN_E * threadIdx.x + x;
             if (p < d.n) d.word_off[p] = e;
             e += v[x];
         }
@@ -1577,7 +1589,7 @@ int phase_sizes(gba_ctx *c, Slot &sl, const Dev &d)
 {
     const gba_scoring &sc = c->sc;
     hipLaunchKernelGGL(k_meta, dim3((d.n + 255) / 256), dim3(256), 0, sl.s, d, sc.mode, sc.kband_k);
-    hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, sl.s, d);
+    hipLaunchKernelGGL(k_scan3, dim3(1), dim3(SCAN_T), 0, sl.s, d);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(sl.h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, sl.s));
     return GBA_OK;
@@ -1598,16 +1610,19 @@ int phase_guide(gba_ctx *c, Slot &sl, Dev &d)
     d.blk_scratch = (gba_block *)sl.b_blk.ptr;
     hipLaunchKernelGGL(k_pack, dim3(d.n), dim3(256), 0, sl.s, d);
     hipLaunchKernelGGL(k_guide, dim3(d.n), dim3(64), 0, sl.s, d, sc.mode, sc.band, sc.max_band, sc.kband_k);
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, sl.s, d, sc.mode == GBA_MODE_AFFINE ? LANE_CLS_AFFINE : LANE_CLS_LINEAR, 1);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(SCAN_T), 0, sl.s, d, sc.mode == GBA_MODE_AFFINE ? LANE_CLS_AFFINE : LANE_CLS_LINEAR, 1);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(sl.h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, sl.s));
     return GBA_OK;
 }
 
-// after the plan has arrived: records arena, then per class the fill launch followed by its
-// traceback.  One launch per non-empty class, widest class first (its few waves run longest);
-// the widest classes go to the slot's auxiliary streams and run beside the bulk on the slot's
-// main stream, which does all its fills first and then its tracebacks.
+// after the plan has arrived: records arena, then one fill launch per non-empty class, widest
+// class first (its few waves run longest): the widest classes go to the slot's auxiliary streams
+// and run beside the bulk on the slot's main stream.  The lane classes share ONE traceback launch
+// on the main stream after all their fills (the pairs of a class are neighbours in `order`, and
+// the traceback does not care about the class); the wave-per-pair class has its own traceback
+// behind its fill.  An auxiliary stream therefore carries fills only, and the next part's wide
+// class, which shares a hardware queue with this one's, does not wait behind a traceback.
 int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_aux)
 {
     const gba_scoring &sc = c->sc;
@@ -1620,20 +1635,21 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
     hipLaunchKernelGGL(k_results_init, dim3((d.n + 255) / 256), dim3(256), 0, s, d, res);
     HIPCHK(c, hipEventRecord(sl.t_fill0, s));
     const bool aff = sc.mode == GBA_MODE_AFFINE;
-    auto launch_tb = [&](int k, hipStream_t st) {
-        const uint32_t cnt = pl.cls_count[k], first = pl.cls_base[k];
-        if (k == CLS_WIDE) {
-            if (aff) hipLaunchKernelGGL(k_traceback_wide<true>, dim3(cnt), dim3(64), 0, st, d, c->tbc, res);
-            else hipLaunchKernelGGL(k_traceback_wide<false>, dim3(cnt), dim3(64), 0, st, d, c->tbc, res);
-            return;
-        }
+    auto launch_tb = [&](int k, hipStream_t st) {          // the wave-per-pair class
+        const uint32_t cnt = pl.cls_count[k];
+        if (aff) hipLaunchKernelGGL(k_traceback_wide<true>, dim3(cnt), dim3(64), 0, st, d, c->tbc, res);
+        else hipLaunchKernelGGL(k_traceback_wide<false>, dim3(cnt), dim3(64), 0, st, d, c->tbc, res);
+    };
+    auto launch_tb_lanes = [&](hipStream_t st) {           // all lane classes: order[0 .. first wave-per-pair pair)
+        const uint32_t cnt = pl.cls_base[CLS_WIDE];
         const dim3 grid((cnt + TB_LANES - 1) / TB_LANES), block(TB_LANES);
-        if (aff) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, st, d, c->tbc, res, first, cnt);
-        else hipLaunchKernelGGL(k_traceback<false>, grid, block, 0, st, d, c->tbc, res, first, cnt);
+        if (aff) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, st, d, c->tbc, res, 0u, cnt);
+        else hipLaunchKernelGGL(k_traceback<false>, grid, block, 0, st, d, c->tbc, res, 0u, cnt);
     };
     HIPCHK(c, hipEventRecord(sl.ev_fork, s));
     bool used[NAUXS] = {};
-    int on_main[NCLS], n_main = 0, nonempty = 0;
+    int nonempty = 0, wide_aux = -1;
+    bool wide_main = false;
     for (int k = 0; k < NCLS; k++) nonempty += pl.cls_count[k] ? 1 : 0;
     uint32_t n_aux = nonempty > 0 ? (uint32_t)nonempty - 1u : 0u;       // the narrowest class stays on the main stream
     if (n_aux > max_aux) n_aux = max_aux;
@@ -1648,7 +1664,7 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
             st = sl.aux[a];
             HIPCHK(c, hipStreamWaitEvent(st, sl.ev_fork, 0));
             used[a] = true;
-        } else on_main[n_main++] = k;
+        }
         if (k == CLS_WIDE) {
             if (aff) hipLaunchKernelGGL(k_fill_wide_affine, dim3(cnt), dim3(64), 0, st, d, c->fc);
             else hipLaunchKernelGGL(k_fill_wide, dim3(cnt), dim3(64), 0, st, d, c->fc);
@@ -1657,17 +1673,20 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
             int rc = launch_fill(c, d, (uint32_t)k, cnt, st);
             if (rc) return rc;
         }
-        if (aux) launch_tb(k, st);
+        if (aux) {
+            if (k == CLS_WIDE) launch_tb(k, st);
+            HIPCHK(c, hipEventRecord(sl.ev_join[sl.launches], st));
+            if (k == CLS_WIDE) wide_aux = (int)sl.launches;
+        } else if (k == CLS_WIDE) wide_main = true;
         sl.launches++;
     }
     HIPCHK(c, hipEventRecord(sl.t_fill1, s));
-    for (int x = 0; x < n_main; x++) launch_tb(on_main[x], s);
+    for (int a = 0; a < NAUXS; a++)
+        if (used[a] && a != wide_aux) HIPCHK(c, hipStreamWaitEvent(s, sl.ev_join[a], 0));
+    if (wide_main) launch_tb(CLS_WIDE, s);
+    if (pl.cls_base[CLS_WIDE] > 0) launch_tb_lanes(s);
     HIPCHK(c, hipGetLastError());
-    for (int a = 0; a < NAUXS; a++) {
-        if (!used[a]) continue;
-        HIPCHK(c, hipEventRecord(sl.ev_join[a], sl.aux[a]));
-        HIPCHK(c, hipStreamWaitEvent(s, sl.ev_join[a], 0));
-    }
+    if (wide_aux >= 0) HIPCHK(c, hipStreamWaitEvent(s, sl.ev_join[wide_aux], 0));
     HIPCHK(c, hipEventRecord(sl.t_tb1, s));
     HIPCHK(c, hipEventRecord(sl.ev_done, s));
     return GBA_OK;
@@ -1771,7 +1790,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
         rc = phase_fill(c, sl, d, res + first, (uint32_t)NAUXS); if (rc) return rc;
         // block offsets continue where the part before stopped
         if (h > 0) HIPCHK(c, hipStreamWaitEvent(sl.s, c->slot[(h - 1) % NSLOT].ev_scan, 0));
-        hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, sl.s, d, needed);
+        hipLaunchKernelGGL(k_scan1, dim3(1), dim3(SCAN_T), 0, sl.s, d, needed);
         HIPCHK(c, hipEventRecord(sl.ev_scan, sl.s));
         hipLaunchKernelGGL(k_emit, dim3(d.n), dim3(256), 0, sl.s, d, res + first, out->blocks, out->blocks_capacity);
         HIPCHK(c, hipGetLastError());
