@@ -1177,6 +1177,12 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
     uint32_t gw = live ? rec[ptr] : 0u;
     uint32_t W = gw & ROW_W_MASK, n = (W + CMASK) >> CSHIFT;   // width, arrow dwords of the current row
     uint32_t state = 0;                           // affine: 0 match state, 1 insertion gap, 2 deletion gap
+    // arrow code -> move, four bits per code: 0 diagonal, codeU up, codeL left; affine codes 3 and 4
+    // change the gap state without moving (3: to the deletion gap, 4: to the insertion gap); the rest are errors
+    uint32_t mvtab = 0;
+    for (uint32_t a = 1; a < (AFF ? 8u : 4u); a++)
+        mvtab |= (a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : (AFF && a <= 4u) ? 3u : 4u) << (4u * a);
+    constexpr uint32_t S0TAB = (2u << 12) | (1u << 16);
     for (;;) {
         const bool active = live && ok && (i | j) != 0u;
         if (!__any(active)) break;
@@ -1221,19 +1227,19 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
             // move: 0 diagonal, 1 up (insertion), 2 left (deletion), 3 none (state change only), 4 error
             uint32_t mv;
             if constexpr (!AFF) {
-                const uint32_t a = cell & 3u;
-                mv = a == 0u ? 0u : a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : 4u;
+                mv = (mvtab >> ((cell & 3u) * 4u)) & 7u;
             } else {
-                const uint32_t a = (cell >> 3) & 7u;
-                const uint32_t m0 = a == 0u ? 0u : a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : a <= 4u ? 3u : 4u;
-                const uint32_t s0 = a == 3u ? 2u : a == 4u ? 1u : 0u;
+                const uint32_t a4 = ((cell >> 3) & 7u) * 4u;
+                const uint32_t m0 = (mvtab >> a4) & 7u;
+                const uint32_t s0 = (S0TAB >> a4) & 3u;
                 const uint32_t st = state;
                 mv = st == 0u ? m0 : st;                                // in a gap state the move is the gap's own
                 state = st == 0u ? s0 : st == 1u ? ((cell & 4u) ? 1u : 0u) : ((cell & 2u) ? 2u : 0u);
             }
             // everything below is selects: one lane's move is another lane's no-op
             const bool isd = mv == 0u, isu = mv == 1u, isl = mv == 2u;
-            const bool bad = !inband || mv == 4u || (i == 0u && (isd || isu)) || (j == 0u && (isd || isl));
+            // a diagonal or up move needs a row above, a diagonal or left move a column to the left
+            const bool bad = (int)!inband | (int)(mv == 4u) | ((int)(i == 0u) & (int)(mv < 2u)) | ((int)(j == 0u) & (int)((mv & 1u) == 0u) & (int)(mv < 3u));
             const bool dmove = isd && !bad, gmove = (isu || isl) && !bad, rowmove = (isd || isu) && !bad;
             ok = !bad;
             const uint32_t qb = (gw >> 10) & 7u;
