@@ -5,7 +5,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from blasr_amd import _lib, refine
+from blasr_amd import _lib, emit, refine
 from blasr_amd.synth import BLOCK_DT
 
 
@@ -85,6 +85,10 @@ def test_refine_alignments_end_to_end(oracle, synth):
         assert c.status == 0 and (c.score, c.nCells, c.nMatch) == (er["score"], er["ncells"], er["n_match"])
         assert np.array_equal(c.blocks["length"], eb["length"]) and np.array_equal(c.blocks["t_pos"], eb["t_pos"])
         assert c.tAlignedSeqPos >= 52 and c.qAlignedSeqPos == 7
+        # the text record of the refined candidate agrees with the statistics the GPU computed
+        ops = emit.cigar_ops(c.blocks, c.qAlignedSeq, c.tAlignedSeq, q_pos=c.qPos, t_pos=c.tPos, allow_adjacent_indels=True)
+        assert sum(n for n, op in ops if op == "=") == c.nMatch and sum(n for n, op in ops if op == "X") == c.nMismatch
+        assert len(emit.m4_line(c, "read", "ref", len(read), 10000).split()) == 13
     assert cands[12].status == _lib.PAIR_EMPTY_GUIDE and len(cands[12].blocks) == 0
     ctx.close()
 
