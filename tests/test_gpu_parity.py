@@ -529,3 +529,40 @@ def test_extra_rescoring_scorers(ctx, api, oracle, synth):
     ok = got["status"] == 0
     nm = got["n_mismatch"].astype(np.int64) + got["n_ins"] + got["n_del"]
     assert np.array_equal(got["extra_score"][ok, 0], nm[ok]) and not got["extra_score"][ok, 1].any()
+
+
+def _pair_with_rows(synth, rows, seed):
+    """A synthetic pair cut so that its DP region has exactly `rows` query bases: the guide's
+    prefix, closed by an 11-base block on the diagonal of the last kept block."""
+    batch = synth.generate(1, read_len=rows + 600, seed=seed)
+    q, t, blk = synth.pair(batch, 0)
+    keep = [b for b in blk if int(b["q_pos"]) + int(b["length"]) <= rows - 40]
+    lq = int(keep[-1]["q_pos"]) + int(keep[-1]["length"])
+    lt = int(keep[-1]["t_pos"]) + int(keep[-1]["length"])
+    keep = [tuple(int(v) for v in b) for b in keep] + [(rows - 11, lt + (rows - 11 - lq), 11)]
+    tl = keep[-1][1] + 11
+    assert tl <= len(t) and keep[0][0] == 0
+    return bytes(q[:rows]), bytes(t[:tl]), keep
+
+
+@pytest.mark.parametrize("mode,limit", [("linear", 65535), ("affine", 32767)])
+def test_maximum_rows(ctx, api, oracle, synth, mode, limit):
+    """The longest DP region the kernels take (65 535 rows, affine 32 767) is bit-exact with the
+    oracle; one row more is handed back untouched with a status of its own."""
+    from blasr_amd import _lib
+    kw = dict(mode=_lib.MODE_AFFINE, band=16) if mode == "affine" else {}
+    ok = _pair_with_rows(synth, limit, 31)
+    over = _pair_with_rows(synth, limit + 1, 32)
+    batch = util.make_batch([ok, over, ok])
+    ctx.set_scoring(api.make_scoring(**kw))
+    pairs, blocks, rc = ctx.refine_host(batch)
+    assert rc == 0
+    assert [int(s) for s in pairs["status"]] == [_lib.PAIR_OK, _lib.PAIR_TOO_LONG, _lib.PAIR_OK]
+    assert int(pairs["rows"][0]) == limit and int(pairs["n_blk"][1]) == 0
+    res, blks = oracle.align(ok[0], ok[1], ok[2], oracle.make_params(**kw))
+    for p in (0, 2):
+        for f in util.FIELDS:
+            assert int(res[f]) == int(pairs[p][f]), (f, p)
+        kb = blocks[int(pairs[p]["blk_off"]):int(pairs[p]["blk_off"]) + int(pairs[p]["n_blk"])]
+        assert np.array_equal(kb["q_pos"], blks["q_pos"]) and np.array_equal(kb["t_pos"], blks["t_pos"])
+        assert np.array_equal(kb["length"], blks["length"])
