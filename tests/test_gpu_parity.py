@@ -566,3 +566,16 @@ def test_maximum_rows(ctx, api, oracle, synth, mode, limit):
         kb = blocks[int(pairs[p]["blk_off"]):int(pairs[p]["blk_off"]) + int(pairs[p]["n_blk"])]
         assert np.array_equal(kb["q_pos"], blks["q_pos"]) and np.array_equal(kb["t_pos"], blks["t_pos"])
         assert np.array_equal(kb["length"], blks["length"])
+
+
+@pytest.mark.parametrize("mode", ["linear", "affine"])
+def test_maximum_width(ctx, api, oracle, synth, mode):
+    """Rows of 1023 cells (band 511) are the widest the kernels take; band 512 makes every row of
+    a pair longer than 1023 cells and the pair comes back TOO_WIDE."""
+    from blasr_amd import _lib
+    kw = dict(mode=_lib.MODE_AFFINE) if mode == "affine" else {}
+    batch = synth.generate(6, read_len=2600, seed=404)
+    _run(ctx, api, oracle, batch, band=511, max_band=511, **kw)
+    ctx.set_scoring(api.make_scoring(band=512, max_band=512, **kw))
+    pairs, blocks, rc = ctx.refine_host(batch)
+    assert rc == 0 and (pairs["status"] == _lib.PAIR_TOO_WIDE).all() and (pairs["n_blk"] == 0).all()
