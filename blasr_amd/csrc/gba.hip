@@ -1134,7 +1134,10 @@ __global__ __launch_bounds__(64) void k_fill_wide_affine(Dev d, FillConst fc)
 // together whenever any lane is about to leave one, one round trip per ~20 rows.
 // Linear records hold 2 bits per cell, affine records one byte per cell (M arrow in bits 3..5,
 // insertion-gap bit 2, deletion-gap bit 1).
-constexpr int TB_RW = 64, TB_TW = 12;
+#ifndef GBA_TB_TSOON
+#define GBA_TB_TSOON 6
+#endif
+constexpr int TB_RW = 64, TB_TW = 12, TB_TSOON = GBA_TB_TSOON;
 #ifndef GBA_TB_LANES
 #define GBA_TB_LANES 64
 #endif
@@ -1188,24 +1191,34 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
         if (!__any(active)) break;
         {
             // linear pairs of the lane classes have rows of at most 8 arrow dwords: always inside the window
-            const int32_t look = AFF ? (int32_t)min(n + 1u, (uint32_t)TB_RW - 1u) : (int32_t)n + 1;
-            if (__any(active && (ptr - look < rb || (int32_t)(j >> 2) - 1 < tb))) {
+            const int32_t look = AFF ? (int32_t)min(n + 1u, (uint32_t)TB_RW - 16u) : (int32_t)n + 1;
+            const int32_t jd = (int32_t)(j >> 2) - 1;
+            if (__any(active && (ptr - look < rb || jd < tb))) {
+                // The walk is bound by these scattered reads (every lane in a record of its own,
+                // 64-byte requests).  The record window starts on a 64-byte boundary, so a refill
+                // is four whole requests (the window still reaches up to ptr: it starts at most 15
+                // dwords higher than it had to); the code window is refilled along with it only
+                // when a lane will leave it within the next ~24 columns.
+                const bool codes = __any(active && jd - TB_TSOON < tb);
                 if (active) {
                     rb = ptr - (TB_RW - 1);
+                    rb += (int32_t)((16u - (uint32_t)((uintptr_t)(rec + rb) >> 2)) & 15u);
                     const uint32_t *src = rec + rb;
 #pragma unroll
                     for (int c = 0; c < TB_RW / 4; c++) {
-                        const u32x4u v = *(const u32x4u *)(src + 4 * c);
+                        const u32x4 v = *(const u32x4 *)(src + 4 * c);
                         uint32_t *w = rwin + (4 * c) * TB_LANES + lane;
                         w[0] = v.x; w[TB_LANES] = v.y; w[2 * TB_LANES] = v.z; w[3 * TB_LANES] = v.w;
                     }
-                    tb = (int32_t)(j >> 2) - (TB_TW - 1);
-                    const uint32_t *ts = tc4 + tb;
+                    if (codes) {
+                        tb = (int32_t)(j >> 2) - (TB_TW - 1);
+                        const uint32_t *ts = tc4 + tb;
 #pragma unroll
-                    for (int c = 0; c < TB_TW / 4; c++) {
-                        const u32x4u v = *(const u32x4u *)(ts + 4 * c);
-                        uint32_t *w = twin + (4 * c) * TB_LANES + lane;
-                        w[0] = v.x; w[TB_LANES] = v.y; w[2 * TB_LANES] = v.z; w[3 * TB_LANES] = v.w;
+                        for (int c = 0; c < TB_TW / 4; c++) {
+                            const u32x4u v = *(const u32x4u *)(ts + 4 * c);
+                            uint32_t *w = twin + (4 * c) * TB_LANES + lane;
+                            w[0] = v.x; w[TB_LANES] = v.y; w[2 * TB_LANES] = v.z; w[3 * TB_LANES] = v.w;
+                        }
                     }
                 }
             }
