@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(64) void k_fill_wide_affine(Dev d, FillConst fc)
 // of the pair's scratch region backwards and come out in forward order.
 //
 // A row's record is [arrow dwords][meta]; rows are walked last to first, so a lane reads its
-// record array backwards.  Every lane keeps the TB_RW record dwords that end at its position and
+// record array backwards.  Every lane keeps TB_RW record dwords that reach up to its position and
 // TB_TW dwords of target codes in an LDS window ([dword][lane]).  A dependent global load per row
 // would cost a full memory round trip per row; instead ALL lanes of the wave refill their windows
 // together whenever any lane is about to leave one, one round trip per ~20 rows.
