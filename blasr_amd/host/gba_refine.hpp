@@ -63,6 +63,47 @@ inline gba_scoring ScoringFromParams(const MappingParameters &p)
     return s;
 }
 
+// CIGAR of a refined candidate, the text the SAM / BAM writers print (the reference calls libcpp's
+// SAMOutput / BAMOutput::PrintAlignment with params.cigarUseSeqMatch and params.allowAdjacentIndels,
+// BlasrUtilsImpl.hpp:970-974).  Gap-free runs are `=` / `X` runs (or one `M`); the gap between two
+// blocks is an insertion, a deletion, or both: adjacent ones are merged unless allowed
+// (RegisterBlasrOptions.h:254-259), i.e. the part they have in common becomes aligned columns.
+// Shape as in the literals of ctest/bamOut.t:21-22; the writers themselves are not in the tree.
+inline std::string CigarString(const AlignmentCandidate &c, bool cigarUseSeqMatch = true, bool allowAdjacentIndels = false,
+                               uint32_t clipLeft = 0, uint32_t clipRight = 0)
+{
+    std::string out;
+    uint32_t runN = 0;
+    char runOp = 0;
+    auto push = [&](uint32_t n, char op) {
+        if (n == 0) return;
+        if (op == runOp) { runN += n; return; }
+        if (runN) out += std::to_string(runN) + runOp;
+        runN = n; runOp = op;
+    };
+    auto columns = [&](uint32_t q, uint32_t t, uint32_t n) {
+        if (!cigarUseSeqMatch) { push(n, 'M'); return; }
+        for (uint32_t k = 0; k < n; k++) push(1, c.qAlignedSeq[q + k] == c.tAlignedSeq[t + k] ? '=' : 'X');
+    };
+    push(clipLeft, 'S');
+    for (size_t b = 0; b < c.blocks.size(); b++) {
+        const uint32_t bq = c.qPos + c.blocks[b].qPos, bt = c.tPos + c.blocks[b].tPos, bl = c.blocks[b].length;
+        columns(bq, bt, bl);
+        if (b + 1 == c.blocks.size()) break;
+        const uint32_t qGap = c.qPos + c.blocks[b + 1].qPos - (bq + bl), tGap = c.tPos + c.blocks[b + 1].tPos - (bt + bl);
+        uint32_t common = 0;
+        if (!allowAdjacentIndels && qGap && tGap) {
+            common = qGap < tGap ? qGap : tGap;
+            columns(bq + bl, bt + bl, common);
+        }
+        push(qGap - common, 'I');
+        push(tGap - common, 'D');
+    }
+    push(clipRight, 'S');
+    if (runN) out += std::to_string(runN) + runOp;
+    return out;
+}
+
 // Collects (read, candidate) pairs of many reads, runs them as one batch.
 class RefineBatch {
 public:

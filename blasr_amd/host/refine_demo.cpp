@@ -2,13 +2,15 @@
 //   n
 //   read  target  nblk  (qPos tPos len)*nblk      -- one candidate per line, one read each
 // refines them in ONE batch and prints per candidate: status score nCells qPos tPos nblk blocks...
+// and, with the argument `cigar`, the two CIGAR forms (adjacent indels merged / allowed) behind them
 #include <cstdio>
 #include <iostream>
 
 #include "gba_refine.hpp"
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool cigar = argc > 1 && std::string(argv[1]) == "cigar";
     size_t n;
     if (!(std::cin >> n)) return 2;
     std::vector<std::string> reads(n);
@@ -31,6 +33,8 @@ int main()
     for (auto &c : cands) {
         std::printf("%d %d %llu %u %u %zu", c.status, c.score, (unsigned long long)c.nCells, c.qPos, c.tPos, c.blocks.size());
         for (auto &b : c.blocks) std::printf(" %u %u %u", b.qPos, b.tPos, b.length);
+        if (cigar && c.status == 0)
+            std::printf(" %s %s", gba::CigarString(c).c_str(), gba::CigarString(c, true, true).c_str());
         std::printf("\n");
     }
     gba_destroy(ctx);

@@ -104,14 +104,19 @@ def test_cpp_host_shim_matches_oracle(oracle, synth):
         q, t, blk = synth.pair(batch, i)
         lines.append("%s %s %d %s" % (bytes(q).decode(), bytes(t).decode(), len(blk),
                                       " ".join("%d %d %d" % (b["q_pos"], b["t_pos"], b["length"]) for b in blk)))
-    out = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120)
+    out = subprocess.run([exe, "cigar"], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     rows = out.stdout.strip().split("\n")
     assert len(rows) == 20
     for i, row in enumerate(rows):
-        v = [int(x) for x in row.split()]
+        *nums, cig_merged, cig_adjacent = row.split()
+        v = [int(x) for x in nums]
         q, t, blk = synth.pair(batch, i)
         er, eb = oracle.align(q, t, blk, oracle.make_params())
         assert v[:6] == [0, er["score"], er["ncells"], er["q_pos"], er["t_pos"], er["n_blk"]]
         got = np.array(v[6:]).reshape(-1, 3)
         assert np.array_equal(got[:, 0], eb["q_pos"]) and np.array_equal(got[:, 2], eb["length"])
+        # the C++ shim's CIGAR is the Python one's, in both forms
+        kw = dict(q_pos=int(er["q_pos"]), t_pos=int(er["t_pos"]))
+        assert cig_merged == emit.cigar(eb, bytes(q), bytes(t), **kw)
+        assert cig_adjacent == emit.cigar(eb, bytes(q), bytes(t), allow_adjacent_indels=True, **kw)
