@@ -1721,7 +1721,7 @@ bool batch_complete(const gba_batch *b)
 // What the timing of a batch is made of, folded in part by part.
 struct TimeAcc {
     float f0 = 1e30f, f1 = 0, tb1 = 0, fill_sum = 0;
-    uint32_t launches = 0;
+    uint32_t launches = 0, wide = 0;
     uint64_t cells = 0, rows = 0, rec = 0;
 };
 
@@ -1734,6 +1734,7 @@ int fold_timing(gba_ctx *c, Slot &sl, TimeAcc &a)
     HIPCHK(c, hipEventElapsedTime(&t, c->ev[0], sl.t_tb1));
     a.f0 = x < a.f0 ? x : a.f0; a.f1 = e > a.f1 ? e : a.f1; a.tb1 = t > a.tb1 ? t : a.tb1;
     a.fill_sum += e - x;
+    a.wide += sl.pl.cls_count[CLS_WIDE];
     a.launches += sl.launches; a.cells += sl.pl.total_cells; a.rows += sl.rows; a.rec += sl.pl.total_rec_dwords * 4;
     return GBA_OK;
 }
@@ -1826,7 +1827,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
         for (int x = 0; x < NSLOT; x++)
             if (used[x]) { int rc = fold_timing(c, c->slot[x], acc); if (rc) return rc; }
         gba_timing &t = c->timing;
-        t.fill_launches = acc.launches; t.cells = acc.cells; t.rows = acc.rows; t.record_bytes = acc.rec;
+        t.fill_launches = acc.launches; t.cells = acc.cells; t.rows = acc.rows; t.record_bytes = acc.rec; t.wide_pairs = acc.wide;
         t.fill_ms = acc.fill_sum; t.traceback_ms = acc.tb1 > acc.f1 ? acc.tb1 - acc.f1 : 0;
         HIPCHK(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[1]));
     }

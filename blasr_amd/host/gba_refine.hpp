@@ -29,6 +29,7 @@ struct MappingParameters {
     int affineOpen = 10, affineExtend = 0;
     int guidedAlignBandSize = 10, bandSize = 16, maxBandSize = 250;
     bool useGuidedAlign = true, refineAlignments = true, sortRefinedAlignments = true;
+    bool doGlobalAlignment = false;
     int maxScore = -200;
     int tieBreak = GBA_TIE_DIAG_LEFT_UP;
 };
@@ -46,20 +47,63 @@ struct AlignmentCandidate {
     int status = 0;
 };
 
+// RefineAlignment never assigns affineOpen / affineExtend of its two DistanceMatrixScoreFunction
+// objects (only idsScoreFn receives params.affineOpen / affineExtend, :643-644; StoreMapQVs does
+// assign them, :120-122, "bug 24363"): both run with what libcpp's constructor leaves there.
+// libcpp is not in the reference tree, so the value is UNPINNED; believed to be 0.
+constexpr int kDistScorerAffineOpen = 0, kDistScorerAffineExtend = 0;      // distScoreFn  (the DP of -affineAlign without QVs)
+constexpr int kStatsScorerAffineOpen = 0, kStatsScorerAffineExtend = 0;    // distScoreFn2 (ComputeAlignmentStats, :733-736)
+
+inline void MatrixFromParams(const MappingParameters &p, gba_scoring &s)
+{
+    for (int a = 0; a < 5; a++)
+        for (int b = 0; b < 5; b++) s.sub[a][b] = (a == 4 || b == 4) ? 0 : (a == b ? p.match : p.mismatch);
+}
+
 inline gba_scoring ScoringFromParams(const MappingParameters &p)
 {
     gba_scoring s{};
-    for (int a = 0; a < 5; a++)
-        for (int b = 0; b < 5; b++) s.sub[a][b] = (a == 4 || b == 4) ? 0 : (a == b ? p.match : p.mismatch);
+    MatrixFromParams(p, s);
     // distScoreFn(SMRTDistanceMatrix, params.deletion, params.insertion), read as ctor(ins, del): :630-631
     s.ins = p.deletion; s.del = p.insertion;
     s.stats_ins = s.stats_del = p.indel;                       // distScoreFn2, :633-634
-    s.affine_open = p.affineOpen; s.affine_extend = p.affineExtend;
+    s.affine_open = kDistScorerAffineOpen; s.affine_extend = kDistScorerAffineExtend;
+    s.stats_affine_open = kStatsScorerAffineOpen; s.stats_affine_extend = kStatsScorerAffineExtend;
     s.band = p.affineAlign ? p.bandSize : p.guidedAlignBandSize;   // :706-731
     s.max_band = p.maxBandSize;
     s.mode = p.affineAlign ? GBA_MODE_AFFINE : GBA_MODE_LINEAR;
     s.tie_break = p.tieBreak;
     s.stats_affine = p.affineAlign ? 1 : 0;
+    return s;
+}
+
+// ComputeDrift(alignmentCandidate) (:654, :793; libcpp AlignmentUtils, not in the tree): the largest
+// distance of a block from the diagonal of the first block.  UNPINNED; restated from the way both
+// call sites use it (the half-width of a diagonal band that must hold the guide).
+inline int ComputeDrift(const std::vector<Block> &blocks)
+{
+    if (blocks.empty()) return 0;
+    const int64_t d0 = (int64_t)blocks[0].tPos - blocks[0].qPos;
+    int64_t m = 0;
+    for (const Block &b : blocks) {
+        const int64_t d = (int64_t)b.tPos - b.qPos - d0;
+        m = std::max(m, d < 0 ? -d : d);
+    }
+    return (int)m;
+}
+
+// KBandAlign(subread, tAlignedSeq, SMRTDistanceMatrix, params.insertion, params.deletion, drift, ...,
+// idsScoreFn, Global) of the -global branch (:657-661), rescored by distScoreFn2 without the affine
+// flag (:663-666).  Of the IDS scorer a read without quality values keeps the matrix and the two
+// explicit gap costs; its per-base quality terms belong to the QV-aware scorers.
+inline gba_scoring ScoringGlobal(const MappingParameters &p, int k)
+{
+    gba_scoring s{};
+    MatrixFromParams(p, s);
+    s.ins = p.insertion; s.del = p.deletion;
+    s.stats_ins = s.stats_del = p.indel;
+    s.mode = GBA_MODE_KBAND; s.kband_k = k;
+    s.tie_break = p.tieBreak;
     return s;
 }
 
@@ -178,10 +222,12 @@ public:
     }
 
 private:
+    // consecutive candidates of one read share its bytes in the arena; "the same read" is decided
+    // by content (a caller may reuse one string buffer for different reads of equal length)
     uint64_t Intern(const std::string &read)
     {
-        if (last_read_ == read.data() && last_len_ == read.size()) return last_base_;
-        last_read_ = read.data(); last_len_ = read.size(); last_base_ = q_arena_.size();
+        if (have_last_ && last_len_ == read.size() && q_arena_.compare(last_base_, last_len_, read) == 0) return last_base_;
+        have_last_ = true; last_len_ = read.size(); last_base_ = q_arena_.size();
         q_arena_ += read;
         return last_base_;
     }
@@ -191,17 +237,85 @@ private:
     std::vector<gba_block> blocks_;
     std::vector<uint64_t> q_off_, t_off_, b_off_;
     std::vector<uint32_t> q_len_, t_len_, n_blk_;
-    const char *last_read_ = nullptr; size_t last_len_ = 0; uint64_t last_base_ = 0;
+    bool have_last_ = false; size_t last_len_ = 0; uint64_t last_base_ = 0;
 };
+
+// The -global branch of RefineAlignment (:648-675) for all candidates of one read: the whole subread
+// against the whole tAlignedSeq in a diagonal band of half-width ComputeDrift(candidate), RemoveEndGaps,
+// rescoring with distScoreFn2; blocks, tPos, qPos (+ SubreadStart) and score are copied back and
+// nothing else of the candidate changes.  One submit per distinct band half-width.
+inline int RefineGlobal(const std::string &read, std::vector<AlignmentCandidate *> &alignmentPtrs,
+                        const MappingParameters &params, gba_ctx *ctx, uint32_t subreadStart = 0, uint32_t subreadLength = UINT32_MAX)
+{
+    if (subreadStart > read.size()) return GBA_E_INVALID;
+    if (subreadLength > read.size() - subreadStart) subreadLength = (uint32_t)(read.size() - subreadStart);
+    std::vector<int> ks;
+    for (AlignmentCandidate *c : alignmentPtrs) ks.push_back(ComputeDrift(c->blocks));
+    std::vector<int> distinct(ks);
+    std::sort(distinct.begin(), distinct.end());
+    distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+    for (int k : distinct) {
+        std::vector<AlignmentCandidate *> cs;
+        for (size_t i = 0; i < ks.size(); i++) if (ks[i] == k) cs.push_back(alignmentPtrs[i]);
+        const uint32_t n = (uint32_t)cs.size();
+        gba_scoring sc = ScoringGlobal(params, k);
+        int rc = gba_set_scoring(ctx, &sc);
+        if (rc != GBA_OK) return rc;
+        std::string t_arena;
+        std::vector<uint64_t> q_off(n, subreadStart), t_off(n), b_off(n, 0);
+        std::vector<uint32_t> q_len(n, subreadLength), t_len(n), n_blk(n, 0);
+        uint64_t cap = n;
+        for (uint32_t i = 0; i < n; i++) {
+            t_off[i] = t_arena.size(); t_len[i] = (uint32_t)cs[i]->tAlignedSeq.size();
+            t_arena += cs[i]->tAlignedSeq;
+            cap += std::min<uint64_t>(subreadLength, t_len[i]);
+        }
+        if (t_arena.empty()) t_arena.push_back('N');
+        const gba_block none{0, 0, 0};
+        gba_batch b{};
+        b.n_pairs = n;
+        b.q_arena = (const uint8_t *)read.data(); b.q_off = q_off.data(); b.q_len = q_len.data();
+        b.t_arena = (const uint8_t *)t_arena.data(); b.t_off = t_off.data(); b.t_len = t_len.data();
+        b.blocks = &none; b.blk_off = b_off.data(); b.n_blk = n_blk.data();
+        b.q_arena_bytes = read.size(); b.t_arena_bytes = t_arena.size(); b.n_blocks_total = 1;
+        if ((rc = gba_submit(ctx, &b)) != GBA_OK) return rc;
+        std::vector<gba_pair_result> pairs(n);
+        std::vector<gba_block> out(cap);
+        gba_results r{pairs.data(), out.data(), cap, 0};
+        if ((rc = gba_wait(ctx, &r)) != GBA_OK) return rc;
+        for (uint32_t i = 0; i < n; i++) {
+            AlignmentCandidate &c = *cs[i];
+            const gba_pair_result &p = pairs[i];
+            c.status = p.status;
+            if (p.status != GBA_PAIR_OK) continue;
+            // RemoveEndGaps (:662): the alignment starts at its first block
+            const uint32_t dq = p.n_blk ? out[p.blk_off].q_pos : 0, dt = p.n_blk ? out[p.blk_off].t_pos : 0;
+            c.blocks.resize(p.n_blk);
+            for (uint32_t x = 0; x < p.n_blk; x++) {
+                const gba_block &g = out[p.blk_off + x];
+                c.blocks[x] = Block{g.q_pos - dq, g.t_pos - dt, g.length};
+            }
+            c.tPos = p.t_pos + dt;
+            c.qPos = p.q_pos + dq + subreadStart;              // :672
+            c.score = p.score;                                 // :673
+        }
+    }
+    return GBA_OK;
+}
 
 // RefineAlignments for ONE read (:905-923): all its candidates in one batch, then the re-sort.
 inline int RefineAlignments(const std::string &read, std::vector<AlignmentCandidate *> &alignmentPtrs,
                             const MappingParameters &params, gba_ctx *ctx)
 {
-    if (!params.refineAlignments || !params.useGuidedAlign) return GBA_E_UNSUPPORTED;
-    RefineBatch batch(ctx);
-    for (AlignmentCandidate *c : alignmentPtrs) batch.Add(read, c);
-    const int rc = batch.Run(params);
+    if (!params.refineAlignments) return GBA_OK;
+    int rc;
+    if (params.doGlobalAlignment) rc = RefineGlobal(read, alignmentPtrs, params, ctx);
+    else if (!params.useGuidedAlign) return GBA_E_UNSUPPORTED;       // legacy k-band branch (:775-902): not on the accelerated path
+    else {
+        RefineBatch batch(ctx);
+        for (AlignmentCandidate *c : alignmentPtrs) batch.Add(read, c);
+        rc = batch.Run(params);
+    }
     if (rc == GBA_OK && params.sortRefinedAlignments)
         std::stable_sort(alignmentPtrs.begin(), alignmentPtrs.end(),
                          [](const AlignmentCandidate *a, const AlignmentCandidate *b) { return a->score < b->score; });

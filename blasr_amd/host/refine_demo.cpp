@@ -2,7 +2,11 @@
 //   n
 //   read  target  nblk  (qPos tPos len)*nblk      -- one candidate per line, one read each
 // refines them in ONE batch and prints per candidate: status score nCells qPos tPos nblk blocks...
-// and, with the argument `cigar`, the two CIGAR forms (adjacent indels merged / allowed) behind them
+// Arguments:
+//   cigar    also print the two CIGAR forms (adjacent indels merged / allowed) behind each candidate
+//   reuse    hand every read to RefineBatch::Add through ONE std::string buffer that is overwritten
+//            for each candidate (what a parsing loop does)
+//   global   run the -global branch (RefineGlobal) on each (read, candidate) instead
 #include <cstdio>
 #include <iostream>
 
@@ -10,7 +14,8 @@
 
 int main(int argc, char **argv)
 {
-    const bool cigar = argc > 1 && std::string(argv[1]) == "cigar";
+    const std::string mode = argc > 1 ? argv[1] : "";
+    const bool cigar = mode == "cigar", reuse = mode == "reuse", global = mode == "global";
     size_t n;
     if (!(std::cin >> n)) return 2;
     std::vector<std::string> reads(n);
@@ -26,9 +31,22 @@ int main(int argc, char **argv)
     int rc = gba_create(&ctx, &cfg);
     if (rc != GBA_OK) { std::fprintf(stderr, "gba_create: %s\n", gba_strerror(rc)); return 1; }
     gba::MappingParameters params;
-    gba::RefineBatch batch(ctx);
-    for (size_t i = 0; i < n; i++) batch.Add(reads[i], &cands[i]);
-    rc = batch.Run(params);
+    if (global) {
+        params.doGlobalAlignment = true;
+        params.sortRefinedAlignments = false;
+        for (size_t i = 0; i < n && rc == GBA_OK; i++) {
+            std::vector<gba::AlignmentCandidate *> one{&cands[i]};
+            rc = gba::RefineAlignments(reads[i], one, params, ctx);
+        }
+    } else {
+        gba::RefineBatch batch(ctx);
+        std::string buffer;
+        for (size_t i = 0; i < n; i++) {
+            if (reuse) { buffer.assign(reads[i]); batch.Add(buffer, &cands[i]); }
+            else batch.Add(reads[i], &cands[i]);
+        }
+        rc = batch.Run(params);
+    }
     if (rc != GBA_OK) { std::fprintf(stderr, "Run: %s\n", gba_strerror(rc)); return 1; }
     for (auto &c : cands) {
         std::printf("%d %d %llu %u %u %zu", c.status, c.score, (unsigned long long)c.nCells, c.qPos, c.tPos, c.blocks.size());

@@ -64,17 +64,50 @@ class AlignmentCandidate:
     status: int = 0
 
 
+# RefineAlignment never assigns affineOpen / affineExtend of its two DistanceMatrixScoreFunction
+# objects (only idsScoreFn receives params.affineOpen / affineExtend, :643-644; StoreMapQVs does
+# assign them, :120-122, under the comment "bug 24363"), so both scorers run with whatever
+# libcpp's constructor leaves there.  libcpp is not in the reference tree: the value is UNPINNED,
+# believed to be 0 (a base-class constructor that zeroes every cost).  One place to change it:
+DIST_SCORER_AFFINE_OPEN = 0        # distScoreFn.affineOpen  in RefineAlignment (DP of -affineAlign without QVs)
+DIST_SCORER_AFFINE_EXTEND = 0      # distScoreFn.affineExtend
+STATS_SCORER_AFFINE_OPEN = 0       # distScoreFn2.affineOpen  (ComputeAlignmentStats(..., params.affineAlign), :733-736)
+STATS_SCORER_AFFINE_EXTEND = 0     # distScoreFn2.affineExtend
+
+
 def scoring_from_params(p: MappingParameters):
     """distScoreFn(SMRTDistanceMatrix, params.deletion, params.insertion) read as ctor(ins, del)
-    (:630-631) and distScoreFn2(indel, indel) (:633-634); band per :706-731."""
+    (:630-631) and distScoreFn2(indel, indel) (:633-634); band per :706-731.  The affine costs of
+    both scorers are the constructor defaults above, NOT params.affineOpen / affineExtend."""
     if p.doGlobalAlignment:
-        raise ValueError("use refine_global() for -global")
+        raise ValueError("the -global branch has its own scorer and band: use scoring_global() / refine_global()")
     mode = _lib.MODE_AFFINE if p.affineAlign else _lib.MODE_LINEAR
     band = p.bandSize if p.affineAlign else p.guidedAlignBandSize
     return make_scoring(match=p.match, mismatch=p.mismatch, ins=p.deletion, dele=p.insertion,
                         indel=p.indel, band=band, max_band=p.maxBandSize, mode=mode,
-                        tie_break=p.tieBreak, affine_open=p.affineOpen, affine_extend=p.affineExtend,
-                        stats_affine=1 if p.affineAlign else 0, sub=p.scoreMatrix)
+                        tie_break=p.tieBreak, affine_open=DIST_SCORER_AFFINE_OPEN, affine_extend=DIST_SCORER_AFFINE_EXTEND,
+                        stats_affine=1 if p.affineAlign else 0, stats_affine_open=STATS_SCORER_AFFINE_OPEN,
+                        stats_affine_extend=STATS_SCORER_AFFINE_EXTEND, sub=p.scoreMatrix)
+
+
+def compute_drift(blocks):
+    """ComputeDrift(alignmentCandidate) (:654, :793; libcpp AlignmentUtils, not in the tree): the
+    largest distance of a block from the diagonal of the first block.  UNPINNED; restated from the
+    way both call sites use it (as the half-width of a diagonal band that must hold the guide)."""
+    if len(blocks) == 0:
+        return 0
+    d0 = int(blocks[0]["t_pos"]) - int(blocks[0]["q_pos"])
+    return max(abs(int(b["t_pos"]) - int(b["q_pos"]) - d0) for b in blocks)
+
+
+def scoring_global(p: MappingParameters, k: int):
+    """KBandAlign(subread, tAlignedSeq, SMRTDistanceMatrix, params.insertion, params.deletion, drift,
+    ..., idsScoreFn, Global) of the -global branch (:657-661), rescored by distScoreFn2 WITHOUT the
+    affine flag (:663-666).  The IDS scorer adds per-base quality terms to insertion / deletion /
+    substitution; for a read without quality values what is left of it is the matrix and the two
+    explicit gap costs, which is what runs here (the QV terms belong to the QV-aware scorers)."""
+    return make_scoring(match=p.match, mismatch=p.mismatch, ins=p.insertion, dele=p.deletion, indel=p.indel,
+                        mode=_lib.MODE_KBAND, kband_k=int(k), tie_break=p.tieBreak, sub=p.scoreMatrix)
 
 
 def build_batch(read: bytes, cands: List[AlignmentCandidate]):
@@ -130,6 +163,11 @@ def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: Mappi
     """Batched RefineAlignments (:905-923): all candidates of the read in one submit."""
     if not params.refineAlignments or not cands:
         return cands
+    if params.doGlobalAlignment:
+        refine_global(read, cands, params, ctx)
+        if params.sortRefinedAlignments:
+            cands.sort(key=lambda c: c.score)
+        return cands
     if not params.useGuidedAlign:
         raise NotImplementedError("the legacy -noUseGuidedAlign branch (:775-902) is not on the accelerated path")
     ctx.set_scoring(scoring_from_params(params))
@@ -138,6 +176,58 @@ def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: Mappi
     copy_back(read, cands, batch, pairs, blocks)
     if params.sortRefinedAlignments:
         cands.sort(key=lambda c: c.score)        # stable, ascending: lower is better (:920-922)
+    return cands
+
+
+def remove_end_gaps(c: AlignmentCandidate):
+    """Alignment::RemoveEndGaps() as :662 uses it: the alignment starts at its first block and ends
+    at its last one; a gap in front of the first block moves into tPos / qPos."""
+    if len(c.blocks) == 0:
+        return
+    dq, dt = int(c.blocks[0]["q_pos"]), int(c.blocks[0]["t_pos"])
+    if dq or dt:
+        c.blocks = c.blocks.copy()
+        c.blocks["q_pos"] -= dq
+        c.blocks["t_pos"] -= dt
+        c.qPos += dq
+        c.tPos += dt
+
+
+def refine_global(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx,
+                  subread_start: int = 0, subread_length: Optional[int] = None):
+    """The -global branch of RefineAlignment (:648-675) for all candidates of a read: the WHOLE
+    subread against the WHOLE tAlignedSeq in a diagonal band of half-width k = ComputeDrift(candidate),
+    RemoveEndGaps, rescoring with distScoreFn2, then blocks / tPos / qPos (+ SubreadStart) / score are
+    copied back; nothing else of the candidate changes.  Candidates whose end cell lies outside their
+    band keep their status (END_OUT_OF_BAND) and are not touched.  One submit per distinct k."""
+    if subread_length is None:
+        subread_length = len(read) - subread_start
+    sub = read[subread_start:subread_start + subread_length]
+    by_k = {}
+    for i, c in enumerate(cands):
+        by_k.setdefault(compute_drift(c.blocks), []).append(i)
+    for k, idx in sorted(by_k.items()):
+        ctx.set_scoring(scoring_global(params, k))
+        n = len(idx)
+        t_parts = [np.frombuffer(cands[i].tAlignedSeq, dtype=np.uint8) for i in idx]
+        t_len = np.array([len(t) for t in t_parts], np.uint32)
+        t_off = np.zeros(n, np.uint64)
+        t_off[1:] = np.cumsum(t_len[:-1], dtype=np.uint64)
+        batch = {"n_pairs": n, "q_arena": np.frombuffer(sub, dtype=np.uint8) if len(sub) else np.zeros(1, np.uint8),
+                 "q_off": np.zeros(n, np.uint64), "q_len": np.full(n, len(sub), np.uint32),
+                 "t_arena": np.concatenate(t_parts) if t_len.sum() else np.zeros(1, np.uint8), "t_off": t_off, "t_len": t_len,
+                 "blocks": np.zeros(1, BLOCK_DT), "blk_off": np.zeros(n, np.uint64), "n_blk": np.zeros(n, np.uint32)}
+        pairs, blocks, rc = ctx.refine_host(batch)
+        for i, r in zip(idx, pairs):
+            c = cands[i]
+            c.status = int(r["status"])
+            if c.status != _lib.PAIR_OK:
+                continue
+            c.blocks = blocks[int(r["blk_off"]):int(r["blk_off"]) + int(r["n_blk"])].copy()
+            c.tPos, c.qPos = int(r["t_pos"]), int(r["q_pos"])
+            remove_end_gaps(c)
+            c.qPos += subread_start                      # :672
+            c.score = int(r["score"])                    # :673
     return cands
 
 

@@ -25,7 +25,8 @@ class _Cfg(C.Structure):
     _fields_ = [("read_len", C.c_uint32), ("p_ins", C.c_double), ("p_del", C.c_double),
                 ("p_sub", C.c_double), ("min_block", C.c_uint32), ("drop_frac", C.c_double),
                 ("seed", C.c_uint64), ("q_stride", C.c_uint32), ("t_stride", C.c_uint32),
-                ("blk_stride", C.c_uint32), ("decoy_every", C.c_uint32), ("len_jitter", C.c_uint32)]
+                ("blk_stride", C.c_uint32), ("decoy_every", C.c_uint32), ("len_jitter", C.c_uint32),
+                ("share_reads", C.c_uint32)]
 
 
 def build(force=False):
@@ -86,9 +87,13 @@ PRESETS = {
 
 def generate(n_pairs, read_len=10000, p_ins=0.09, p_del=0.04, p_sub=0.02, min_block=11,
              drop_frac=0.10, seed=2000, ref_len=ECOLI_LEN, n_frac=0.0, decoy_every=0,
-             len_jitter=0, threads=8, ref=None, **_ignored):
+             len_jitter=0, threads=8, ref=None, share_reads=False, **_ignored):
     """Generate `n_pairs` pairs.  Returns a dict with q_arena, q_off, q_len, t_arena,
-    t_off, t_len, blocks, blk_off, n_blk, n_pairs."""
+    t_off, t_len, blocks, blk_off, n_blk, n_pairs, plus win_start / win_rc (each target as a
+    window of the reference: start on the forward strand, strand flag) and read_id (pairs with
+    the same id are candidates of one read).  With decoy_every = k, pairs p with p % k != 0 are
+    decoys: random loci with sparse guides; with share_reads they are further candidates of the
+    true pair's read (they view its query bytes), otherwise unrelated random reads."""
     lib = _load()
     if ref is None:
         ref = reference(ref_len, REF_SEED, n_frac)
@@ -96,7 +101,7 @@ def generate(n_pairs, read_len=10000, p_ins=0.09, p_del=0.04, p_sub=0.02, min_bl
     t_stride = int(read_len * 1.35) + 256
     blk_stride = read_len // min_block + 2
     cfg = _Cfg(read_len, p_ins, p_del, p_sub, min_block, drop_frac, seed, q_stride, t_stride,
-               blk_stride, decoy_every, len_jitter)
+               blk_stride, decoy_every, len_jitter, 1 if share_reads else 0)
     b = {
         "n_pairs": n_pairs,
         "q_arena": np.zeros(n_pairs * q_stride, dtype=np.uint8),
@@ -105,17 +110,22 @@ def generate(n_pairs, read_len=10000, p_ins=0.09, p_del=0.04, p_sub=0.02, min_bl
         "q_off": np.zeros(n_pairs, dtype=np.uint64), "q_len": np.zeros(n_pairs, dtype=np.uint32),
         "t_off": np.zeros(n_pairs, dtype=np.uint64), "t_len": np.zeros(n_pairs, dtype=np.uint32),
         "blk_off": np.zeros(n_pairs, dtype=np.uint64), "n_blk": np.zeros(n_pairs, dtype=np.uint32),
+        "win_start": np.zeros(n_pairs, dtype=np.uint64), "win_rc": np.zeros(n_pairs, dtype=np.uint8),
     }
+    idx = np.arange(n_pairs, dtype=np.uint32)
+    b["read_id"] = idx - idx % decoy_every if (share_reads and decoy_every) else idx
     p = lambda a: a.ctypes.data_as(C.c_void_p)
 
     def run(first, count):
         return lib.gbs_generate(p(ref), C.c_uint64(len(ref)), C.byref(cfg), C.c_uint32(first),
                                 C.c_uint32(count), p(b["q_arena"]), p(b["q_off"]), p(b["q_len"]),
                                 p(b["t_arena"]), p(b["t_off"]), p(b["t_len"]),
-                                p(b["blocks"]), p(b["blk_off"]), p(b["n_blk"]))
+                                p(b["blocks"]), p(b["blk_off"]), p(b["n_blk"]), p(b["win_start"]), p(b["win_rc"]))
 
     threads = max(1, min(threads, n_pairs))
     chunk = (n_pairs + threads - 1) // threads
+    if decoy_every:
+        chunk = (chunk + decoy_every - 1) // decoy_every * decoy_every     # a read's candidates in one job
     jobs = [(i, min(chunk, n_pairs - i)) for i in range(0, n_pairs, chunk)]
     if len(jobs) == 1:
         bad = [run(*jobs[0])]
@@ -131,6 +141,15 @@ def preset(name, n_pairs, **over):
     cfg = dict(PRESETS[name])
     cfg.update(over)
     return generate(n_pairs, **cfg), cfg
+
+
+def as_windows(batch):
+    """The same batch with its targets given as windows of the reference (for a context that holds
+    the reference: no t_arena; t_off = window start on the forward strand, t_rc = strand)."""
+    w = {k: batch[k] for k in ("n_pairs", "q_arena", "q_off", "q_len", "t_len", "blocks", "blk_off", "n_blk")}
+    w["t_off"] = batch["win_start"]
+    w["t_rc"] = batch["win_rc"]
+    return w
 
 
 def pair(batch, i):

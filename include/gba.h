@@ -159,6 +159,7 @@ typedef struct {
     uint64_t cells;             /* sum of ncells over pairs with status OK */
     uint64_t rows;              /* DP rows of the batch */
     uint64_t record_bytes;      /* traceback bytes the fill kernels wrote */
+    uint32_t wide_pairs;        /* pairs that ran in the wave-per-pair kernels (band rows too wide for a lane) */
 } gba_timing;
 
 /* Replaces the per-thread `MappingBuffers mappingBuffers;` (Blasr.cpp:771): device

@@ -89,6 +89,57 @@ def test_c5_band250(ctx, api, oracle, synth):
     _run(ctx, api, oracle, batch, band=250, tie_break=1, ins=3, dele=6)
 
 
+@pytest.mark.parametrize("band,n", [(100, 8), (250, 8)])
+def test_c5_50kb_full_length(ctx, api, oracle, synth, band, n):
+    """The ultra-long configuration at its own size: 50 kb reads at 20 % error, band 100 and band 250,
+    every pair through the wave-per-pair kernels, bit for bit against the oracle (whose matrices take
+    ~125 MB per pair at band 250)."""
+    batch, cfg = synth.preset("c5_50kb_wide", n)
+    pairs, _ = _run(ctx, api, oracle, batch, band=band)
+    assert int((pairs["status"] == 0).sum()) == n
+    assert int(pairs["rows"].min()) > 45_000 and int(pairs["ncells"].min()) > 45_000 * (2 * band)
+    assert ctx.timing()["wide_pairs"] == n
+
+
+def test_c4_reference_windows_chr20(ctx, api, oracle, synth):
+    """The chr20-sized configuration the way it runs: a 64 Mb reference with N runs resident on the
+    device, ten candidates per read (the true locus and nine decoys that view the same read), targets
+    given as (start, length, strand) windows, about half of them on the reverse strand."""
+    n = 400
+    ref = synth.reference(synth.CHR20_LEN, n_frac=0.01)
+    batch = synth.generate(n, read_len=10_000, seed=4000, decoy_every=10, share_reads=True, ref=ref)
+    assert 100 < int(batch["win_rc"].sum()) < 300 and len(np.unique(batch["read_id"])) == 40
+    ctx.set_scoring(api.make_scoring())
+    ctx.set_reference(ref)
+    try:
+        pairs, blocks, rc = ctx.refine_host(synth.as_windows(batch))
+    finally:
+        ctx.set_reference(None)
+    assert rc == 0
+    util.compare_batch(oracle, batch, oracle.make_params(), pairs, blocks)     # the oracle aligns the spelled-out targets
+    assert int((pairs["status"] == 0).sum()) >= n - 5
+    # a window that starts inside an N run of the reference is handled like any other
+    touches_n = [p for p in range(n) if (synth.pair(batch, p)[1] == ord("N")).any()]
+    assert all(int(pairs["status"][p]) in (0, 3) for p in touches_n)
+
+
+def test_recorded_fuzz_mismatches(ctx, api, oracle, synth):
+    """Every pair on which a randomised run once disagreed with the oracle, replayed alone and at
+    the batch position it had (second pair, between unrelated pairs), several times."""
+    cases = json.load(open(os.path.join(GOLD, "fuzz_regressions.json")))["cases"]
+    fill = synth.generate(6, read_len=300, seed=12)
+    fillers = [tuple(synth.pair(fill, i)) for i in range(6)]
+    fillers = [(bytes(q), bytes(t), [tuple(int(v) for v in b) for b in blk]) for q, t, blk in fillers]
+    for c in cases:
+        kw = dict(c["scoring"])
+        me = (c["q"], c["t"], [tuple(b) for b in c["blocks"]])
+        for lst in ([me], fillers[:1] + [me] + fillers[1:]):
+            batch = util.make_batch(lst)
+            for _ in range(4):
+                pairs, _ = _run(ctx, api, oracle, batch, **kw)
+            assert int(pairs[1 if len(lst) > 1 else 0]["status"]) == 0, c["name"]
+
+
 def test_affine_wide_bands(ctx, api, oracle, synth):
     """Affine rows wider than the lane-per-pair classes: the wave-per-pair affine kernel."""
     from blasr_amd import _lib

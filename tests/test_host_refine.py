@@ -22,8 +22,26 @@ def test_scoring_from_params_defaults():
     assert (s.ins, s.dele, s.stats_ins, s.stats_del) == (5, 4, 5, 5)
     assert (s.band, s.mode) == (10, _lib.MODE_LINEAR)
     assert s.sub[0][0] == -5 and s.sub[0][1] == 6 and s.sub[4][2] == 0
-    a = refine.scoring_from_params(refine.MappingParameters(affineAlign=True))
+    a = refine.scoring_from_params(refine.MappingParameters(affineAlign=True, affineOpen=7, affineExtend=3))
     assert (a.band, a.mode, a.stats_affine) == (16, _lib.MODE_AFFINE, 1)
+    # RefineAlignment never hands params.affineOpen / affineExtend to the distance-matrix scorers
+    # (BlasrUtilsImpl.hpp:630-634 against :643-644): constructor defaults, named in refine.py
+    assert (a.affine_open, a.affine_extend) == (refine.DIST_SCORER_AFFINE_OPEN, refine.DIST_SCORER_AFFINE_EXTEND) == (0, 0)
+    assert (a.stats_affine_open, a.stats_affine_extend) == (0, 0)
+    with pytest.raises(ValueError):
+        refine.scoring_from_params(refine.MappingParameters(doGlobalAlignment=True))
+    g = refine.scoring_global(refine.MappingParameters(), 37)
+    # KBandAlign(..., params.insertion, params.deletion, drift, ...) BlasrUtilsImpl.hpp:657-661
+    assert (g.mode, g.kband_k, g.ins, g.dele, g.stats_ins, g.stats_affine) == (_lib.MODE_KBAND, 37, 4, 5, 5, 0)
+
+
+def test_compute_drift_and_remove_end_gaps():
+    assert refine.compute_drift(_blocks([])) == 0
+    assert refine.compute_drift(_blocks([(0, 0, 10), (12, 15, 5), (30, 28, 4)])) == 3
+    assert refine.compute_drift(_blocks([(5, 9, 10), (20, 20, 5)])) == 4
+    c = refine.AlignmentCandidate(tAlignedSeq=b"", blocks=_blocks([(2, 5, 4), (8, 11, 3)]), qPos=1, tPos=10)
+    refine.remove_end_gaps(c)
+    assert (c.qPos, c.tPos) == (3, 15) and [tuple(b) for b in c.blocks] == [(0, 0, 4), (6, 6, 3)]
 
 
 def test_build_batch_slicing_rules():
@@ -91,6 +109,84 @@ def test_refine_alignments_end_to_end(oracle, synth):
         assert len(emit.m4_line(c, "read", "ref", len(read), 10000).split()) == 13
     assert cands[12].status == _lib.PAIR_EMPTY_GUIDE and len(cands[12].blocks) == 0
     ctx.close()
+
+
+def _global_expect(oracle, sub, t, blk, p):
+    """What the -global branch must leave in a candidate, from the oracle's k-band alignment."""
+    k = refine.compute_drift(blk)
+    P = oracle.make_params(mode=oracle.MODE_KBAND, kband_k=k, ins=p.insertion, dele=p.deletion, indel=p.indel)
+    r, b = oracle.align(sub, t, [], P)
+    if r["status"] != 0:
+        return r["status"], None
+    dq, dt = (int(b[0]["q_pos"]), int(b[0]["t_pos"])) if len(b) else (0, 0)
+    return 0, (r["score"], dq, dt, [(int(x["q_pos"]) - dq, int(x["t_pos"]) - dt, int(x["length"])) for x in b])
+
+
+@pytest.mark.gpu
+def test_refine_global_branch(oracle, synth):
+    """-global (BlasrUtilsImpl.hpp:648-675): whole subread against the whole window, k = ComputeDrift,
+    RemoveEndGaps, qPos += SubreadStart; Python mirror and C++ shim against the oracle."""
+    from blasr_amd import api, build
+    ctx = api.Context(0)
+    batch = synth.generate(10, read_len=600, len_jitter=200, seed=777)
+    p = refine.MappingParameters(doGlobalAlignment=True, sortRefinedAlignments=False)
+    lines = ["10"]
+    for i in range(10):
+        q, t, blk = synth.pair(batch, i)
+        q, t = bytes(q), bytes(t)
+        if i % 3 == 1:
+            t = b"ACGTTGCA" + t            # a leading target-only stretch: the alignment starts with a gap
+            blk = blk.copy(); blk["t_pos"] += 8
+        read = b"TTTTT" + q + b"GG"
+        c = refine.AlignmentCandidate(tAlignedSeq=t, blocks=blk.copy(), score=12345, nCells=7, tAlignedSeqPos=99)
+        refine.refine_global(read, [c], p, ctx, subread_start=5, subread_length=len(q))
+        st, e = _global_expect(oracle, q, t, blk, p)
+        assert c.status == st
+        lines.append("%s %s %d %s" % (q.decode(), t.decode(), len(blk), " ".join("%d %d %d" % tuple(b) for b in blk)))
+        if st != 0:
+            assert c.score == 12345
+            continue
+        score, dq, dt, eb = e
+        assert (c.score, c.qPos, c.tPos) == (score, dq + 5, dt)
+        assert [tuple(int(v) for v in b) for b in c.blocks] == eb
+        assert (c.nCells, c.tAlignedSeqPos, c.tAlignedSeq) == (7, 99, t)       # untouched by this branch
+    ctx.close()
+    out = subprocess.run([build.HOST_DEMO, "global"], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    for i, row in enumerate(out.stdout.strip().split("\n")):
+        v = [int(x) for x in row.split()]
+        q, t, nb = lines[i + 1].split()[:3]
+        blk = _blocks([tuple(int(x) for x in lines[i + 1].split()[3 + 3 * j:6 + 3 * j]) for j in range(int(nb))])
+        st, e = _global_expect(oracle, q.encode(), t.encode(), blk, p)
+        assert v[0] == st
+        if st == 0:
+            score, dq, dt, eb = e
+            assert (v[1], v[3], v[4], v[5]) == (score, dq, dt, len(eb))
+            assert [tuple(x) for x in np.array(v[6:]).reshape(-1, 3)] == eb
+
+
+@pytest.mark.gpu
+def test_cpp_shim_with_one_reused_read_buffer(oracle, synth):
+    """A caller that hands every read to RefineBatch::Add through one std::string it overwrites
+    (equal lengths: same data pointer, same size) must still get every read aligned as itself."""
+    from blasr_amd import build
+    batch = synth.generate(6, read_len=400, seed=55)
+    L = int(batch["q_len"].min())
+    lines = ["6"]
+    cases = []
+    for i in range(6):
+        q, t, blk = synth.pair(batch, i)
+        q = bytes(q)[:L]
+        blk = np.array([b for b in blk if int(b["q_pos"]) + int(b["length"]) <= L], dtype=BLOCK_DT)
+        tl = int(blk[-1]["t_pos"]) + int(blk[-1]["length"])
+        cases.append((q, bytes(t)[:tl], blk))
+        lines.append("%s %s %d %s" % (q.decode(), bytes(t).decode(), len(blk), " ".join("%d %d %d" % tuple(b) for b in blk)))
+    out = subprocess.run([build.HOST_DEMO, "reuse"], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    for (q, t, blk), row in zip(cases, out.stdout.strip().split("\n")):
+        v = [int(x) for x in row.split()]
+        er, eb = oracle.align(q, t, blk, oracle.make_params())
+        assert v[:6] == [0, er["score"], er["ncells"], er["q_pos"], er["t_pos"], er["n_blk"]]
 
 
 @pytest.mark.gpu
