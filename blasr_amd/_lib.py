@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GBA_LIB", os.path.join(_HERE, "libgba.so"))   # GBA_LIB: experiment builds
 
 # return codes / statuses / modes (include/gba.h)
-OK, E_INVALID, E_NOMEM, E_HIP, E_NOSPACE, E_UNSUPPORTED, E_STATE = 0, -1, -2, -3, -4, -5, -6
+OK, E_INVALID, E_NOMEM, E_HIP, E_NOSPACE, E_UNSUPPORTED, E_STATE, E_TOOBIG = 0, -1, -2, -3, -4, -5, -6, -7
+NOALLOC_SCRATCH_BYTES = 64 << 20
 (PAIR_OK, PAIR_EMPTY_GUIDE, PAIR_BAD_GUIDE, PAIR_UNREACHABLE, PAIR_NOSPACE,
  PAIR_END_OUT_OF_BAND, PAIR_TOO_WIDE, PAIR_TOO_LONG) = range(8)
 MODE_LINEAR, MODE_AFFINE, MODE_KBAND = 0, 1, 2
@@ -76,7 +77,7 @@ class Timing(C.Structure):
 
 
 EXPORTS = ("gba_create", "gba_destroy", "gba_set_scoring", "gba_submit", "gba_wait",
-           "gba_submit_device", "gba_set_reference", "gba_get_timing", "gba_last_hip_error", "gba_strerror", "gba_version")
+           "gba_submit_device", "gba_submit_device_noalloc", "gba_set_reference", "gba_get_timing", "gba_last_hip_error", "gba_strerror", "gba_version")
 
 _lib = None
 
@@ -103,6 +104,7 @@ def lib():
         L.gba_submit.argtypes = [C.c_void_p, C.POINTER(Batch)]
         L.gba_wait.argtypes = [C.c_void_p, C.POINTER(Results)]
         L.gba_submit_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Results)]
+        L.gba_submit_device_noalloc.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Results)]
         L.gba_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.gba_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         L.gba_last_hip_error.argtypes = [C.c_void_p]

@@ -132,11 +132,13 @@ class Context:
         return pairs, blocks[:min(self.blocks_needed, int(blocks_capacity))], rc
 
     # ---- device-resident tensors
-    def refine_device(self, dbatch, out_pairs, out_blocks):
+    def refine_device(self, dbatch, out_pairs, out_blocks, no_alloc=False):
         """dbatch: dict of torch CUDA tensors with the same keys as a host batch (uint8 arenas;
         offsets/lengths as int64/int32 tensors holding the uint64/uint32 bit patterns; blocks as
         an int32 tensor [n_blocks, 3]).  out_pairs: uint8 tensor of n*PAIR_RESULT_DT.itemsize
-        bytes; out_blocks: int32 tensor [capacity, 3].  Returns (rc, blocks_needed)."""
+        bytes; out_blocks: int32 tensor [capacity, 3].  Returns (rc, blocks_needed).
+        no_alloc: through gba_submit_device_noalloc (fixed scratch, no device allocation; a batch
+        that does not fit raises GbaError with code E_TOOBIG)."""
         n = int(dbatch["n_pairs"])
         ta = dbatch.get("t_arena")
         trc = dbatch.get("t_rc")
@@ -147,7 +149,8 @@ class Context:
                   trc.data_ptr() if trc is not None else None)
         assert out_pairs.numel() * out_pairs.element_size() >= n * PAIR_RESULT_DT.itemsize
         r = Results(out_pairs.data_ptr(), out_blocks.data_ptr(), out_blocks.shape[0], 0)
-        rc = self._check(self._L.gba_submit_device(self._h, C.byref(b), C.byref(r)), allow=(_lib.E_NOSPACE,))
+        fn = self._L.gba_submit_device_noalloc if no_alloc else self._L.gba_submit_device
+        rc = self._check(fn(self._h, C.byref(b), C.byref(r)), allow=(_lib.E_NOSPACE,))
         return rc, int(r.blocks_needed)
 
 

@@ -1497,6 +1497,12 @@ struct Buf {
     size_t cap = 0;
 };
 
+// Scratch of gba_submit_device_noalloc: every buffer that entry point needs beyond the caller's
+// inputs and outputs is carved from this array, one copy per GPU, held until the process ends.
+// Host code never uses the array's name as an address: gba_create asks the runtime for the
+// address on its device (hipGetSymbolAddress) and everything below works with that pointer.
+static __device__ __align__(256) unsigned char scratch[GBA_NOALLOC_SCRATCH_BYTES];
+
 }  // namespace
 
 constexpr int NSLOT = 2;      // a large batch is run in parts that alternate between two slots, staggered, so that one
@@ -1545,6 +1551,11 @@ struct gba_ctx {
     uint64_t flight_needed = 0;
     hipEvent_t ev[2] = {};           // start and end of a batch
     gba_timing timing = {};
+    // gba_submit_device_noalloc: address of this device's copy of `scratch` (null: the lookup failed)
+    // and, while such a call runs, the bytes already handed out (fixed_on: ensure() carves, never allocates)
+    unsigned char *fixed_base = nullptr;
+    size_t fixed_used = 0;
+    bool fixed_on = false;
 };
 
 namespace {
@@ -1557,6 +1568,15 @@ namespace {
 
 int ensure(gba_ctx *c, Buf &b, size_t bytes)
 {
+    if (c->fixed_on) {
+        // no-allocation mode: a fresh 256-byte aligned piece of the fixed scratch per request
+        if (bytes <= b.cap) return GBA_OK;
+        const size_t at = (c->fixed_used + 255) & ~size_t(255);
+        if (bytes > GBA_NOALLOC_SCRATCH_BYTES || at > GBA_NOALLOC_SCRATCH_BYTES - bytes) return GBA_E_TOOBIG;
+        b.ptr = c->fixed_base + at; b.cap = bytes;
+        c->fixed_used = at + bytes;
+        return GBA_OK;
+    }
     if (bytes <= b.cap) return GBA_OK;
     if (b.ptr) { HIPCHK(c, hipFree(b.ptr)); b.ptr = nullptr; b.cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
@@ -1780,7 +1800,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     g.word_off = (uint64_t *)c->b_pair64[4].ptr;
     const bool timing = (c->flags & GBA_FLAG_TIMING) != 0;
     uint32_t parts = 1;
-    if (c->part_pairs && n > c->part_pairs + c->part_pairs / 15) {
+    if (!c->fixed_on && c->part_pairs && n > c->part_pairs + c->part_pairs / 15) {
         parts = (uint32_t)(((uint64_t)n + c->part_pairs / 2) / c->part_pairs);
         if (parts < 2) parts = 2;
     }
@@ -1850,6 +1870,7 @@ const char *gba_strerror(int code)
     case GBA_E_NOSPACE: return "block arena too small";
     case GBA_E_UNSUPPORTED: return "scoring not supported by the kernels";
     case GBA_E_STATE: return "call out of sequence";
+    case GBA_E_TOOBIG: return "batch needs more scratch than the fixed no-allocation buffer holds";
     case GBA_PAIR_EMPTY_GUIDE: return "pair: empty guide";
     case GBA_PAIR_BAD_GUIDE: return "pair: malformed guide";
     case GBA_PAIR_UNREACHABLE: return "pair: end cell unreachable inside the band";
@@ -1878,6 +1899,11 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
         if (hipHostMalloc((void **)&c->h_needed, 8) != hipSuccess) { rc = GBA_E_NOMEM; break; }
         for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rc = GBA_E_HIP; break; }
         if (rc) break;
+        {   // this device's copy of the no-allocation scratch (the ctx stays usable without it)
+            void *sp = nullptr;
+            if (hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) == hipSuccess) c->fixed_base = (unsigned char *)sp;
+            else (void)hipGetLastError();
+        }
         if (const char *e = getenv("GBA_PART_PAIRS")) c->part_pairs = (uint32_t)strtoul(e, nullptr, 10);
         for (int h = 0; h < NSLOT && !rc; h++) {
             Slot &sl = c->slot[h];
@@ -1997,6 +2023,31 @@ int gba_submit_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     if (!batch_complete(b)) return GBA_E_INVALID;
     if (!b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
     return run_device(c, b, out);
+}
+
+int gba_submit_device_noalloc(gba_ctx *c, const gba_batch *b, gba_results *out)
+{
+    if (!c || !b || !out) return GBA_E_INVALID;
+    if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
+    if (b->n_pairs && (!out->pairs || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
+    if (!batch_complete(b)) return GBA_E_INVALID;
+    if (!b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
+    if (!c->fixed_base) return GBA_E_HIP;             // hipGetSymbolAddress failed in gba_create
+    // The ctx's own (allocated, grow-only) buffers are set aside for the duration of the call and the
+    // same pipeline runs on buffers carved from the fixed scratch, as one part on slot 0.
+    Buf *all[14 + 5 + 1 + 5 * NSLOT];
+    Buf saved[14 + 5 + 1 + 5 * NSLOT];
+    int k = 0;
+    for (auto &x : c->b_pair32) all[k++] = &x;
+    for (auto &x : c->b_pair64) all[k++] = &x;
+    all[k++] = &c->b_needed;
+    for (auto &sl : c->slot) { all[k++] = &sl.b_plan; all[k++] = &sl.b_guide; all[k++] = &sl.b_tc; all[k++] = &sl.b_rec; all[k++] = &sl.b_blk; }
+    for (int i = 0; i < k; i++) { saved[i] = *all[i]; *all[i] = Buf(); }
+    c->fixed_on = true; c->fixed_used = 0;
+    const int rc = run_device(c, b, out);
+    c->fixed_on = false;
+    for (int i = 0; i < k; i++) *all[i] = saved[i];
+    return rc;
 }
 
 int gba_submit(gba_ctx *c, const gba_batch *b)

@@ -31,7 +31,8 @@ enum {
     GBA_E_HIP = -3,          /* a HIP call failed; gba_last_hip_error() has the code */
     GBA_E_NOSPACE = -4,      /* caller's block arena too small; gba_results.blocks_needed says how big */
     GBA_E_UNSUPPORTED = -5,  /* scoring outside what the kernels implement */
-    GBA_E_STATE = -6         /* wait without submit, submit while a batch is in flight, ... */
+    GBA_E_STATE = -6,        /* wait without submit, submit while a batch is in flight, ... */
+    GBA_E_TOOBIG = -7        /* gba_submit_device_noalloc: the batch needs more scratch than GBA_NOALLOC_SCRATCH_BYTES */
 };
 
 /* per-pair status (gba_pair_result.status) */
@@ -187,6 +188,19 @@ int gba_wait(gba_ctx *ctx, gba_results *out);
  * memory (all pointers in `dev_batch` and `dev_out` are device pointers).
  * Returns when the batch has completed; out->blocks_needed is filled in. */
 int gba_submit_device(gba_ctx *ctx, const gba_batch *dev_batch, gba_results *dev_out);
+
+/* gba_submit_device for callers that cannot allocate device memory while they run (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid it).  It has no counterpart in the
+ * reference.  Same arguments, results and return codes as gba_submit_device, but it calls no
+ * hipMalloc / hipFree: all scratch (per-pair arrays, guide stream, target codes, traceback records,
+ * block scratch) is carved from a fixed array of GBA_NOALLOC_SCRATCH_BYTES that every GPU the
+ * library runs on holds from load until the process ends.  A batch that needs more returns
+ * GBA_E_TOOBIG and leaves the outputs untouched (roughly 330 bytes of scratch per query base at the
+ * default band: about 190 pairs of 10 kb, or 13 000 of 150 b).  The batch runs in one piece.  All
+ * calls on one GPU share that GPU's array, whichever ctx they come through: calls that overlap in
+ * time on one GPU race; calls one after the other are independent (nothing is carried over). */
+#define GBA_NOALLOC_SCRATCH_BYTES (64u << 20)
+int gba_submit_device_noalloc(gba_ctx *ctx, const gba_batch *dev_batch, gba_results *dev_out);
 
 /* Keeps a copy of the reference (genome, ASCII; `ref` is a host pointer) in device
  * memory for batches whose t_arena is NULL; len == 0 drops it.  Replaces the
