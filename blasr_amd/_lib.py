@@ -77,7 +77,7 @@ class Timing(C.Structure):
 
 
 EXPORTS = ("gba_create", "gba_destroy", "gba_set_scoring", "gba_submit", "gba_wait",
-           "gba_submit_device", "gba_submit_device_noalloc", "gba_set_reference", "gba_get_timing", "gba_last_hip_error", "gba_strerror", "gba_version")
+           "gba_submit_device", "gba_submit_device_noalloc", "gba_host_alloc", "gba_host_free", "gba_set_reference", "gba_get_timing", "gba_last_hip_error", "gba_strerror", "gba_version")
 
 _lib = None
 
@@ -101,8 +101,12 @@ def lib():
         L.gba_destroy.argtypes = [C.c_void_p]
         L.gba_destroy.restype = None
         L.gba_set_scoring.argtypes = [C.c_void_p, C.POINTER(Scoring)]
-        L.gba_submit.argtypes = [C.c_void_p, C.POINTER(Batch)]
-        L.gba_wait.argtypes = [C.c_void_p, C.POINTER(Results)]
+        L.gba_submit.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Results)]
+        L.gba_wait.argtypes = [C.c_void_p]
+        L.gba_host_alloc.argtypes = [C.c_void_p, C.c_uint64]
+        L.gba_host_alloc.restype = C.c_void_p
+        L.gba_host_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.gba_host_free.restype = None
         L.gba_submit_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Results)]
         L.gba_submit_device_noalloc.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Results)]
         L.gba_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]

@@ -1,6 +1,8 @@
 """Host-side handle over the C-ABI: one Context per (worker, GPU), as include/gba.h asks.
 
-`Context.refine_host` takes numpy batches (gba_submit / gba_wait, H2D + D2H inside);
+`Context.refine_host` takes numpy batches (gba_submit / gba_wait, H2D + D2H inside;
+`Context.submit_host` / `Context.wait_host` are the two halves, `Context.host_array` gives
+page-locked numpy arrays from gba_host_alloc);
 `Context.refine_device` takes torch CUDA tensors that already live in HBM
 (gba_submit_device).  torch is used for device memory and streams only.
 """
@@ -116,20 +118,58 @@ class Context:
         return {f[0]: getattr(t, f[0]) for f in Timing._fields_}
 
     # ---- host buffers in, host buffers out
+    def host_array(self, shape, dtype):
+        """A numpy array in page-locked memory of the ctx (gba_host_alloc): batches and result
+        buffers built in such arrays travel at the full rate of the link.  Valid until close()."""
+        dtype = np.dtype(dtype)
+        count = int(np.prod(shape))
+        nbytes = max(count * dtype.itemsize, 1)
+        p = self._L.gba_host_alloc(self._h, nbytes)
+        if not p:
+            raise GbaError(_lib.E_NOMEM, self._L.gba_last_hip_error(self._h))
+        buf = (C.c_uint8 * nbytes).from_address(p)
+        return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+
+    def pinned_copy(self, batch):
+        """The batch with every array copied into page-locked memory of the ctx."""
+        out = {"n_pairs": int(batch["n_pairs"])}
+        for k, dt in (("q_arena", np.uint8), ("t_arena", np.uint8), ("blocks", BLOCK_DT), ("q_off", np.uint64),
+                      ("t_off", np.uint64), ("blk_off", np.uint64), ("q_len", np.uint32), ("t_len", np.uint32),
+                      ("n_blk", np.uint32), ("t_rc", np.uint8)):
+            if batch.get(k) is not None:
+                a = self.host_array(np.shape(batch[k]), dt)
+                a[...] = batch[k]
+                out[k] = a
+        return out
+
+    def submit_host(self, batch, pairs, blocks):
+        """gba_submit: returns at once; `pairs` (ndarray[PAIR_RESULT_DT], one per pair) and `blocks`
+        (ndarray[BLOCK_DT]) are filled while the batch runs and must not be read before
+        wait_host() has returned."""
+        b, keep = make_batch_struct(batch)
+        r = Results(_ptr(pairs), _ptr(blocks) if len(blocks) else None, len(blocks), 0)
+        self._check(self._L.gba_submit(self._h, C.byref(b), C.byref(r)))
+        self._flight = (b, keep, r, pairs, blocks)       # everything the running batch points into
+
+    def wait_host(self):
+        """gba_wait: blocks until the submitted batch is complete.  Returns (rc, blocks_needed)."""
+        rc = self._check(self._L.gba_wait(self._h), allow=(_lib.E_NOSPACE,))
+        r = self._flight[2]
+        self._flight = None
+        self.blocks_needed = int(r.blocks_needed)
+        return rc, self.blocks_needed
+
     def refine_host(self, batch, blocks_capacity=None):
         """batch: dict of numpy arrays (see blasr_amd.synth.generate).  Returns
         (pairs ndarray[PAIR_RESULT_DT], blocks ndarray[BLOCK_DT], rc)."""
         n = int(batch["n_pairs"])
-        b, keep = make_batch_struct(batch)
-        self._check(self._L.gba_submit(self._h, C.byref(b)))
         if blocks_capacity is None:
-            blocks_capacity = int(keep["q_len"].astype(np.uint64).sum()) + n
+            blocks_capacity = int(np.asarray(batch["q_len"]).astype(np.uint64).sum()) + n
         pairs = np.zeros(n, dtype=PAIR_RESULT_DT)
-        blocks = np.zeros(max(int(blocks_capacity), 1), dtype=BLOCK_DT)
-        r = Results(_ptr(pairs), _ptr(blocks), int(blocks_capacity), 0)
-        rc = self._check(self._L.gba_wait(self._h, C.byref(r)), allow=(_lib.E_NOSPACE,))
-        self.blocks_needed = int(r.blocks_needed)
-        return pairs, blocks[:min(self.blocks_needed, int(blocks_capacity))], rc
+        blocks = np.zeros(int(blocks_capacity), dtype=BLOCK_DT)
+        self.submit_host(batch, pairs, blocks)
+        rc, needed = self.wait_host()
+        return pairs, blocks[:min(needed, int(blocks_capacity))], rc
 
     # ---- device-resident tensors
     def refine_device(self, dbatch, out_pairs, out_blocks, no_alloc=False):

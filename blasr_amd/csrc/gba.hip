@@ -28,7 +28,11 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "../../include/gba.h"
 
@@ -135,7 +139,12 @@ __device__ __forceinline__ uint64_t tc_offset(const Dev &d, uint32_t p) { return
 // DP region of each pair.  Guided modes: from the first block's start to the last block's end
 // (AlignmentToGuide: tStart/qStart = first block, tEnd/qEnd = last block end).  k-band: the
 // whole q x t rectangle.  Also an upper bound on the pair's guide stream length.
-__global__ void k_meta(Dev d, int mode, int kband_k)
+//
+// score_a / score_b bound what a cell word can hold: a path makes Q row moves, each adding at most
+// 128 (the bias of the substitution table) + score_a, and up to T moves along a row, each adding at
+// most score_b; the sum must stay below score_lim (the value from which words count as unreachable),
+// otherwise the pair is TOO_LONG.
+__global__ void k_meta(Dev d, int mode, int kband_k, uint32_t score_a, uint32_t score_b, uint32_t score_lim)
 {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= d.n) return;
@@ -177,6 +186,7 @@ __global__ void k_meta(Dev d, int mode, int kband_k)
         }
     }
     if (st == GBA_PAIR_OK && (Q > (mode == GBA_MODE_AFFINE ? MAX_ROWS_AFFINE : MAX_ROWS) || T > MAX_COLS)) st = GBA_PAIR_TOO_LONG;
+    if (st == GBA_PAIR_OK && (uint64_t)Q * (128u + score_a) + (uint64_t)T * score_b >= score_lim) st = GBA_PAIR_TOO_LONG;
     d.status[p] = st; d.qS[p] = qS; d.tS[p] = tS; d.Q[p] = Q; d.T[p] = T;
     d.rows[p] = st == GBA_PAIR_OK ? Q + 1 : 0;
     d.cols[p] = st == GBA_PAIR_OK ? T + 1 : 0;
@@ -1512,9 +1522,15 @@ constexpr int NAUXS = 2;      // auxiliary streams per slot (wider classes run b
 // Everything one (half) batch in flight needs of its own.
 struct Slot {
     Buf b_plan, b_guide, b_tc, b_rec, b_blk;     // device scratch (grow-only)
+    Buf b_out;                                   // host-buffer batches: the packed blocks of the part in this slot, on their way to the host
     Plan *h_plan = nullptr;                      // pinned
+    uint64_t *h_cnt = nullptr;                   // pinned: blocks of the batch up to and including the part in this slot
     hipStream_t s = nullptr, aux[NAUXS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[NAUXS] = {}, ev_done = nullptr, ev_scan = nullptr;
+    hipEvent_t ev_cnt = nullptr, ev_emit = nullptr, ev_d2h = nullptr;   // host-buffer batches: count read back; blocks packed; blocks copied out
+    bool d2h_pending = false;                    // ev_d2h has been recorded for a copy out of b_out
+    Dev dev;                                     // the part in this slot (kept for its deferred block emission)
+    uint32_t first = 0;                          // its first pair
     hipEvent_t t_fill0 = nullptr, t_fill1 = nullptr, t_tb1 = nullptr;
     Plan pl;                                     // host copy of the half batch's plan
     uint64_t rows = 0;
@@ -1532,6 +1548,7 @@ struct gba_ctx {
     gba_scoring sc;
     FillConst fc;
     TbConst tbc;
+    uint32_t score_a = 0, score_b = 0;   // largest cost of a row move / of a move along a row (k_meta's score-range check)
     uint32_t part_pairs = 122880;    // a batch of more than ~1.07 x this many pairs is run in staggered parts of about this
                                      // size (env GBA_PART_PAIRS, 0 = never).  Two lane-per-pair waves per SIMD is what the GPU
                                      // can use (1920 waves here); measured on 10-kb pairs: 245 760 pairs in one piece 658 GCUPS,
@@ -1542,13 +1559,20 @@ struct gba_ctx {
     Buf s_trc;
     Buf b_pair32[14], b_pair64[5], b_needed;
     Slot slot[NSLOT];
-    // staging for the host-pointer path
-    Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res, s_out;
+    // host-buffer batches: device copies of the caller's batch, the copy streams, the worker thread
+    Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res;
+    hipStream_t s_in = nullptr, s_out = nullptr;     // host-to-device and device-to-host copies, beside the kernels
+    std::vector<hipEvent_t> ev_in;                   // per part: its inputs have arrived
+    std::vector<void *> host_allocs;                 // gba_host_alloc
     uint64_t *h_needed = nullptr;    // pinned
-    bool in_flight = false;
-    uint32_t flight_n = 0;
-    int flight_rc = 0;
-    uint64_t flight_needed = 0;
+    bool in_flight = false;          // a host-buffer batch has been submitted and not yet waited for
+    std::thread worker;              // runs host-buffer batches, so that gba_submit returns at once
+    std::mutex mu;
+    std::condition_variable cv;
+    bool job_ready = false, job_done = false, quit = false;
+    gba_batch job_batch = {};
+    gba_results *job_out = nullptr;
+    int job_rc = 0;
     hipEvent_t ev[2] = {};           // start and end of a batch
     gba_timing timing = {};
     // gba_submit_device_noalloc: address of this device's copy of `scratch` (null: the lookup failed)
@@ -1627,7 +1651,8 @@ Dev sub_dev(const Dev &g, uint32_t p0, uint32_t cnt, Slot &sl)
 int phase_sizes(gba_ctx *c, Slot &sl, const Dev &d)
 {
     const gba_scoring &sc = c->sc;
-    hipLaunchKernelGGL(k_meta, dim3((d.n + 255) / 256), dim3(256), 0, sl.s, d, sc.mode, sc.kband_k);
+    hipLaunchKernelGGL(k_meta, dim3((d.n + 255) / 256), dim3(256), 0, sl.s, d, sc.mode, sc.kband_k, c->score_a, c->score_b,
+                       (uint32_t)(UNREACH >> (sc.mode == GBA_MODE_AFFINE ? 6 : 5)));
     hipLaunchKernelGGL(k_scan3, dim3(1), dim3(SCAN_T), 0, sl.s, d);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(sl.h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, sl.s));
@@ -1759,12 +1784,101 @@ int fold_timing(gba_ctx *c, Slot &sl, TimeAcc &a)
     return GBA_OK;
 }
 
+// Host-buffer batches: what run_device needs to move a batch in and its results out part by part.
+struct HostIO {
+    const gba_batch *hb;          // the caller's batch (host pointers)
+    gba_results *hout;            // the caller's result buffers (host pointers)
+    gba_pair_result *d_res;       // device copy of the pair results
+    uint64_t need_before = 0;     // blocks of the parts emitted so far
+    // byte / element ranges of the three arenas that are on the device already
+    uint64_t have[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+};
+
+// Copies what part [first, first + cnt) of a host batch needs and the device does not have yet:
+// the per-pair arrays of the part and the stretch of each arena its pairs point into (arenas are
+// normally laid out in pair order, so consecutive parts need consecutive stretches; whatever lies
+// between the stretch on the device and the new one is copied too, so one interval stays valid).
+int stage_part(gba_ctx *c, HostIO &io, uint32_t first, uint32_t cnt, hipEvent_t done)
+{
+    const gba_batch &b = *io.hb;
+    hipStream_t st = c->s_in;
+    struct { Buf *buf; const void *src; size_t esz; } per_pair[] = {
+        {&c->s_qoff, b.q_off, 8}, {&c->s_toff, b.t_off, 8}, {&c->s_boff, b.blk_off, 8},
+        {&c->s_qlen, b.q_len, 4}, {&c->s_tlen, b.t_len, 4}, {&c->s_nblk, b.n_blk, 4}, {&c->s_trc, b.t_rc, 1}};
+    for (auto &x : per_pair)
+        if (x.src) HIPCHK(c, hipMemcpyAsync((char *)x.buf->ptr + (size_t)first * x.esz, (const char *)x.src + (size_t)first * x.esz,
+                                            (size_t)cnt * x.esz, hipMemcpyHostToDevice, st));
+    struct { int which; Buf *buf; const uint8_t *src; uint64_t extent; size_t esz; const uint64_t *off; const uint32_t *len; } arena[] = {
+        {0, &c->s_q, b.q_arena, b.q_arena_bytes, 1, b.q_off, b.q_len},
+        {1, &c->s_t, b.t_arena, b.t_arena_bytes, 1, b.t_off, b.t_len},
+        {2, &c->s_blk, (const uint8_t *)b.blocks, b.n_blocks_total, sizeof(gba_block), b.blk_off, b.n_blk}};
+    for (auto &a : arena) {
+        if (!a.src) continue;                        // no target arena: windows of the ctx reference
+        uint64_t lo = ~0ull, hi = 0;
+        for (uint32_t p = first; p < first + cnt; p++) {
+            const uint64_t o = a.off[p], l = a.len[p];
+            if (l == 0 || o > a.extent || l > a.extent - o) continue;      // the kernels refuse such a pair without touching it
+            lo = o < lo ? o : lo; hi = o + l > hi ? o + l : hi;
+        }
+        if (lo >= hi) continue;
+        uint64_t *have = io.have[a.which];
+        uint64_t pieces[2][2]; int np = 0;
+        if (have[0] >= have[1]) { pieces[np][0] = lo; pieces[np][1] = hi; np++; have[0] = lo; have[1] = hi; }
+        else {
+            if (lo < have[0]) { pieces[np][0] = lo; pieces[np][1] = have[0]; np++; have[0] = lo; }
+            if (hi > have[1]) { pieces[np][0] = have[1]; pieces[np][1] = hi; np++; have[1] = hi; }
+        }
+        for (int k = 0; k < np; k++)
+            HIPCHK(c, hipMemcpyAsync((char *)a.buf->ptr + pieces[k][0] * a.esz, a.src + pieces[k][0] * a.esz,
+                                     (size_t)(pieces[k][1] - pieces[k][0]) * a.esz, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(c, hipEventRecord(done, st));
+    return GBA_OK;
+}
+
+// Deferred end of the part in `sl` (host-buffer batches): its block count has been read back, so
+// its blocks are packed into a device buffer of exactly that size and both the pair results and
+// the blocks go to the caller's buffers on the device-to-host stream.
+int finish_part(gba_ctx *c, HostIO &io, Slot &sl)
+{
+    HIPCHK(c, hipEventSynchronize(sl.ev_cnt));
+    const uint64_t after = *sl.h_cnt, before = io.need_before, cnt = after - before;
+    const uint64_t cap = io.hout->blocks_capacity;
+    const uint64_t fit = before >= cap ? 0 : (after <= cap ? cnt : cap - before);     // blocks of this part the caller's arena takes
+    if (sl.d2h_pending) {
+        // the previous part of this slot may still be copying out of b_out
+        if ((size_t)cnt * sizeof(gba_block) > sl.b_out.cap) HIPCHK(c, hipEventSynchronize(sl.ev_d2h));
+        else HIPCHK(c, hipStreamWaitEvent(sl.s, sl.ev_d2h, 0));
+    }
+    { int rc = ensure(c, sl.b_out, (size_t)cnt * sizeof(gba_block) + 16); if (rc) return rc; }
+    // offsets are those of the whole batch (that is what the caller's arena is indexed by), so the
+    // part's buffer is addressed as if it began `before` blocks earlier
+    hipLaunchKernelGGL(k_emit, dim3(sl.dev.n), dim3(256), 0, sl.s, sl.dev, io.d_res + sl.first, (gba_block *)sl.b_out.ptr - before, cap);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(sl.ev_emit, sl.s));
+    HIPCHK(c, hipEventRecord(sl.ev_done, sl.s));
+    HIPCHK(c, hipStreamWaitEvent(c->s_out, sl.ev_emit, 0));
+    HIPCHK(c, hipMemcpyAsync(io.hout->pairs + sl.first, io.d_res + sl.first, (size_t)sl.dev.n * sizeof(gba_pair_result),
+                             hipMemcpyDeviceToHost, c->s_out));
+    if (fit && io.hout->blocks)
+        HIPCHK(c, hipMemcpyAsync(io.hout->blocks + before, sl.b_out.ptr, (size_t)fit * sizeof(gba_block), hipMemcpyDeviceToHost, c->s_out));
+    HIPCHK(c, hipEventRecord(sl.ev_d2h, c->s_out));
+    sl.d2h_pending = true;
+    io.need_before = after;
+    return GBA_OK;
+}
+
 // Runs one batch whose inputs and outputs are device pointers.  A batch much larger than
 // gba_ctx::part_pairs is run in parts of about that size which alternate between the two slots:
 // a part's target packing and guide construction are enqueued while the part before it fills, and
 // its traceback and block copy run under the fill of the part after it; a slot's scratch is reused
 // by every second part.  The host waits twice per part (arena sizes, launch grids) and once at the end.
-int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
+//
+// With `io` the batch comes from and goes to host buffers (b and out then hold the device copies'
+// addresses): the inputs of part h + 1 are copied in while part h is being launched, and a part's
+// blocks are packed and copied out one part later, once its block count has been read back, so
+// copies in both directions run beside the kernels of the parts around them.
+int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nullptr)
 {
     const uint32_t n = b->n_pairs;
     out->blocks_needed = 0;
@@ -1812,6 +1926,15 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     TimeAcc acc;
     bool used[NSLOT] = {};
 
+    if (io) {
+        while (c->ev_in.size() < parts) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->ev_in.push_back(e);
+        }
+        for (auto &sl : c->slot) sl.d2h_pending = false;
+        int rc = stage_part(c, *io, 0, n < per ? n : per, c->ev_in[0]); if (rc) return rc;
+    }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
     HIPCHK(c, hipMemsetAsync(needed, 0, 8, s));
     if (parts > 1) {                                   // the second slot's stream starts after the batch's inputs are ready
@@ -1822,24 +1945,39 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out)
         Slot &sl = c->slot[h % NSLOT];
         const uint32_t first = h * per, cnt = n - first < per ? n - first : per;
         Dev d = sub_dev(g, first, cnt, sl);
+        if (io) HIPCHK(c, hipStreamWaitEvent(sl.s, c->ev_in[h], 0));
         int rc = phase_sizes(c, sl, d); if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(sl.s));         // the sizes are here, and the slot's previous part has completed
         if (timing && used[h % NSLOT]) { rc = fold_timing(c, sl, acc); if (rc) return rc; }
         used[h % NSLOT] = true;
         rc = phase_guide(c, sl, d); if (rc) return rc;
         rc = phase_fill(c, sl, d, res + first, (uint32_t)NAUXS); if (rc) return rc;
+        if (io && h + 1 < parts) {       // the next part's inputs travel while this part runs
+            const uint32_t nf = (h + 1) * per;
+            rc = stage_part(c, *io, nf, n - nf < per ? n - nf : per, c->ev_in[h + 1]); if (rc) return rc;
+        }
         // block offsets continue where the part before stopped
         if (h > 0) HIPCHK(c, hipStreamWaitEvent(sl.s, c->slot[(h - 1) % NSLOT].ev_scan, 0));
         hipLaunchKernelGGL(k_scan1, dim3(1), dim3(SCAN_T), 0, sl.s, d, needed);
         HIPCHK(c, hipEventRecord(sl.ev_scan, sl.s));
+        if (io) {
+            sl.dev = d; sl.first = first;
+            HIPCHK(c, hipMemcpyAsync(sl.h_cnt, needed, 8, hipMemcpyDeviceToHost, sl.s));
+            HIPCHK(c, hipEventRecord(sl.ev_cnt, sl.s));
+            HIPCHK(c, hipEventRecord(sl.ev_done, sl.s));
+            if (h > 0) { rc = finish_part(c, *io, c->slot[(h - 1) % NSLOT]); if (rc) return rc; }
+            continue;
+        }
         hipLaunchKernelGGL(k_emit, dim3(d.n), dim3(256), 0, sl.s, d, res + first, out->blocks, out->blocks_capacity);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(sl.ev_done, sl.s));
     }
+    if (io) { int rc = finish_part(c, *io, c->slot[(parts - 1) % NSLOT]); if (rc) return rc; }
     if (parts > 1) HIPCHK(c, hipStreamWaitEvent(s, c->slot[1].ev_done, 0));
     HIPCHK(c, hipMemcpyAsync(c->h_needed, needed, 8, hipMemcpyDeviceToHost, s));
     if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     HIPCHK(c, hipStreamSynchronize(s));
+    if (io) HIPCHK(c, hipStreamSynchronize(c->s_out));
     out->blocks_needed = *c->h_needed;
     if (timing) {
         // fill: the bulk fill launches of the parts, one after the other (what else runs on the GPU
@@ -1904,13 +2042,16 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
             if (hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) == hipSuccess) c->fixed_base = (unsigned char *)sp;
             else (void)hipGetLastError();
         }
+        if (hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking) != hipSuccess) { rc = GBA_E_HIP; break; }
         if (const char *e = getenv("GBA_PART_PAIRS")) c->part_pairs = (uint32_t)strtoul(e, nullptr, 10);
         for (int h = 0; h < NSLOT && !rc; h++) {
             Slot &sl = c->slot[h];
             if (h == 0) sl.s = c->stream;
             else if (hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking) != hipSuccess) { rc = GBA_E_HIP; break; }
             if (hipHostMalloc((void **)&sl.h_plan, sizeof(Plan)) != hipSuccess) { rc = GBA_E_NOMEM; break; }
-            hipEvent_t *plain[] = {&sl.ev_fork, &sl.ev_done, &sl.ev_scan, &sl.ev_join[0], &sl.ev_join[1]};
+            if (hipHostMalloc((void **)&sl.h_cnt, 8) != hipSuccess) { rc = GBA_E_NOMEM; break; }
+            hipEvent_t *plain[] = {&sl.ev_fork, &sl.ev_done, &sl.ev_scan, &sl.ev_join[0], &sl.ev_join[1], &sl.ev_cnt, &sl.ev_emit, &sl.ev_d2h};
             for (hipEvent_t *e : plain) if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) rc = GBA_E_HIP;
             hipEvent_t *timed[] = {&sl.t_fill0, &sl.t_fill1, &sl.t_tb1};
             for (hipEvent_t *e : timed) if (hipEventCreate(e) != hipSuccess) rc = GBA_E_HIP;
@@ -1926,13 +2067,26 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
 void gba_destroy(gba_ctx *c)
 {
     if (!c) return;
+    if (c->worker.joinable()) {
+        {
+            std::unique_lock<std::mutex> lk(c->mu);
+            if (c->in_flight) c->cv.wait(lk, [c] { return c->job_done; });
+            c->quit = true;
+            c->cv.notify_all();
+        }
+        c->worker.join();
+    }
     (void)hipSetDevice(c->device);
+    if (c->s_in) { (void)hipStreamSynchronize(c->s_in); (void)hipStreamDestroy(c->s_in); }
+    if (c->s_out) { (void)hipStreamSynchronize(c->s_out); (void)hipStreamDestroy(c->s_out); }
+    for (hipEvent_t e : c->ev_in) (void)hipEventDestroy(e);
+    for (void *p : c->host_allocs) (void)hipHostFree(p);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &b : c->b_pair32) release(b);
     for (auto &b : c->b_pair64) release(b);
     Buf *bs[] = {&c->b_ref, &c->s_trc, &c->b_needed,
                  &c->s_q, &c->s_t, &c->s_blk, &c->s_qoff, &c->s_toff, &c->s_boff, &c->s_qlen, &c->s_tlen,
-                 &c->s_nblk, &c->s_res, &c->s_out};
+                 &c->s_nblk, &c->s_res};
     for (Buf *b : bs) release(*b);
     if (c->h_needed) (void)hipHostFree(c->h_needed);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1940,10 +2094,12 @@ void gba_destroy(gba_ctx *c)
         Slot &sl = c->slot[h];
         for (int a = 0; a < NAUXS; a++) if (sl.aux[a]) { (void)hipStreamSynchronize(sl.aux[a]); (void)hipStreamDestroy(sl.aux[a]); }
         if (h > 0 && sl.s) { (void)hipStreamSynchronize(sl.s); (void)hipStreamDestroy(sl.s); }
-        Buf *sb[] = {&sl.b_plan, &sl.b_guide, &sl.b_tc, &sl.b_rec, &sl.b_blk};
+        Buf *sb[] = {&sl.b_plan, &sl.b_guide, &sl.b_tc, &sl.b_rec, &sl.b_blk, &sl.b_out};
         for (Buf *b : sb) release(*b);
         if (sl.h_plan) (void)hipHostFree(sl.h_plan);
-        hipEvent_t evs[] = {sl.ev_fork, sl.ev_done, sl.ev_scan, sl.ev_join[0], sl.ev_join[1], sl.t_fill0, sl.t_fill1, sl.t_tb1};
+        if (sl.h_cnt) (void)hipHostFree(sl.h_cnt);
+        hipEvent_t evs[] = {sl.ev_fork, sl.ev_done, sl.ev_scan, sl.ev_join[0], sl.ev_join[1], sl.t_fill0, sl.t_fill1, sl.t_tb1,
+                            sl.ev_cnt, sl.ev_emit, sl.ev_d2h};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1961,8 +2117,10 @@ int gba_set_scoring(gba_ctx *c, const gba_scoring *s)
     if (s->band < 0 || s->max_band < 0 || s->band > 30000 || s->max_band > 30000) return GBA_E_INVALID;
     if (s->mode == GBA_MODE_KBAND && (s->kband_k < 0 || s->kband_k > 30000)) return GBA_E_INVALID;
     // The fill kernels keep substitution costs in a +128-biased byte table and cell words in int32
-    // with 5 low tag bits; |cost| <= 127 and at most 65535 rows keep every reachable word below
-    // UNREACH and every word inside int32.
+    // with 5 low tag bits (affine: 6): |cost| <= 127 keeps the table in bytes.  Whether a pair's
+    // scores fit the word is a per-pair matter (rows x row-move cost + columns x deletion cost,
+    // k_meta): at the default costs every pair up to the row limit fits; at |cost| = 127 a pair
+    // with many columns per row may not, and is handed back TOO_LONG.
     for (int a = 0; a < 5; a++)
         for (int b = 0; b < 5; b++)
             if (s->sub[a][b] < -128 || s->sub[a][b] > 127) return GBA_E_UNSUPPORTED;
@@ -1977,6 +2135,17 @@ int gba_set_scoring(gba_ctx *c, const gba_scoring *s)
     }
     // nothing of the ctx changes before this point: a refused scoring leaves the previous one in force
     c->sc = *s;
+    {
+        auto mag = [](int32_t v) { return (uint32_t)(v < 0 ? -v : v); };
+        uint32_t a = mag(s->ins);
+        for (int x = 0; x < 5; x++) for (int y = 0; y < 5; y++) a = a > mag(s->sub[x][y]) ? a : mag(s->sub[x][y]);
+        uint32_t b = mag(s->del);
+        if (s->mode == GBA_MODE_AFFINE) {
+            const uint32_t oe = (uint32_t)(s->affine_open + s->affine_extend);       // checked: 0..63
+            a = a > oe ? a : oe; b = b > oe ? b : oe;
+        }
+        c->score_a = a; c->score_b = b;
+    }
     const uint32_t codeL = s->tie_break == GBA_TIE_DIAG_LEFT_UP ? 1u : 2u, codeU = 3u - codeL;
     FillConst &f = c->fc;
     for (int a = 0; a < 5; a++) {
@@ -2050,80 +2219,120 @@ int gba_submit_device_noalloc(gba_ctx *c, const gba_batch *b, gba_results *out)
     return rc;
 }
 
-int gba_submit(gba_ctx *c, const gba_batch *b)
+// Body of a host-buffer batch, on the ctx's worker thread: device copies of the caller's arrays
+// (grow-only), then the pipeline of run_device with the copies in both directions inside it.
+static int run_host_batch(gba_ctx *c, const gba_batch *b, gba_results *out)
 {
-    if (!c || !b) return GBA_E_INVALID;
-    if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
-    if (!batch_complete(b)) return GBA_E_INVALID;
-    if (b->n_pairs && !b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
     const uint32_t n = b->n_pairs;
+    out->blocks_needed = 0;
+    if (n == 0) return GBA_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    c->flight_n = n; c->flight_rc = GBA_OK; c->flight_needed = 0;
-    if (n == 0) { c->in_flight = true; return GBA_OK; }
     int rc;
-    struct { Buf *buf; const void *src; size_t bytes; } cp[] = {
-        {&c->s_q, b->q_arena, (size_t)b->q_arena_bytes}, {&c->s_t, b->t_arena, (size_t)b->t_arena_bytes},
-        {&c->s_blk, b->blocks, (size_t)b->n_blocks_total * sizeof(gba_block)},
-        {&c->s_qoff, b->q_off, (size_t)n * 8}, {&c->s_toff, b->t_off, (size_t)n * 8}, {&c->s_boff, b->blk_off, (size_t)n * 8},
-        {&c->s_qlen, b->q_len, (size_t)n * 4}, {&c->s_tlen, b->t_len, (size_t)n * 4}, {&c->s_nblk, b->n_blk, (size_t)n * 4}};
-    if (!b->t_arena) { cp[1].src = nullptr; cp[1].bytes = 0; }      // windows of the ctx reference: nothing to stage
-    for (auto &x : cp) {
-        if ((rc = ensure(c, *x.buf, x.bytes + 16))) return rc;
-        if (x.bytes) HIPCHK(c, hipMemcpyAsync(x.buf->ptr, x.src, x.bytes, hipMemcpyHostToDevice, c->stream));
-    }
-    // worst case one block per base of the shorter sequence (lengths that cannot be real count as 0)
-    uint64_t cap = 0;
-    for (uint32_t p = 0; p < n; p++) {
-        const uint64_t ql = b->q_len[p] <= b->q_arena_bytes ? b->q_len[p] : 0, tl = b->t_len[p];
-        cap += (ql < tl ? ql : tl) + 1;
-    }
-    if ((rc = ensure(c, c->s_res, (size_t)n * sizeof(gba_pair_result)))) return rc;
-    if ((rc = ensure(c, c->s_out, (size_t)cap * sizeof(gba_block)))) return rc;
+    struct { Buf *buf; size_t bytes; } need[] = {
+        {&c->s_q, (size_t)b->q_arena_bytes}, {&c->s_t, b->t_arena ? (size_t)b->t_arena_bytes : 0},
+        {&c->s_blk, (size_t)b->n_blocks_total * sizeof(gba_block)},
+        {&c->s_qoff, (size_t)n * 8}, {&c->s_toff, (size_t)n * 8}, {&c->s_boff, (size_t)n * 8},
+        {&c->s_qlen, (size_t)n * 4}, {&c->s_tlen, (size_t)n * 4}, {&c->s_nblk, (size_t)n * 4},
+        {&c->s_trc, b->t_rc ? (size_t)n : 0}, {&c->s_res, (size_t)n * sizeof(gba_pair_result)}};
+    for (auto &x : need) if ((rc = ensure(c, *x.buf, x.bytes + 16))) return rc;
     gba_batch db = *b;
     db.q_arena = (const uint8_t *)c->s_q.ptr; db.t_arena = b->t_arena ? (const uint8_t *)c->s_t.ptr : nullptr;
-    if (b->t_rc) {
-        if ((rc = ensure(c, c->s_trc, (size_t)n + 16))) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->s_trc.ptr, b->t_rc, n, hipMemcpyHostToDevice, c->stream));
-        db.t_rc = (const uint8_t *)c->s_trc.ptr;
-    }
+    db.t_rc = b->t_rc ? (const uint8_t *)c->s_trc.ptr : nullptr;
     db.blocks = (const gba_block *)c->s_blk.ptr;
     db.q_off = (const uint64_t *)c->s_qoff.ptr; db.t_off = (const uint64_t *)c->s_toff.ptr;
     db.blk_off = (const uint64_t *)c->s_boff.ptr;
     db.q_len = (const uint32_t *)c->s_qlen.ptr; db.t_len = (const uint32_t *)c->s_tlen.ptr;
     db.n_blk = (const uint32_t *)c->s_nblk.ptr;
     gba_results dr;
-    dr.pairs = (gba_pair_result *)c->s_res.ptr; dr.blocks = (gba_block *)c->s_out.ptr;
-    dr.blocks_capacity = cap; dr.blocks_needed = 0;
-    rc = run_device(c, &db, &dr);
-    if (rc != GBA_OK && rc != GBA_E_NOSPACE) return rc;
-    c->flight_rc = rc; c->flight_needed = dr.blocks_needed;
+    dr.pairs = (gba_pair_result *)c->s_res.ptr; dr.blocks = nullptr;
+    dr.blocks_capacity = out->blocks_capacity; dr.blocks_needed = 0;
+    HostIO io;
+    io.hb = b; io.hout = out; io.d_res = dr.pairs;
+    rc = run_device(c, &db, &dr, &io);
+    out->blocks_needed = dr.blocks_needed;
+    return rc;
+}
+
+static void worker_main(gba_ctx *c)
+{
+    std::unique_lock<std::mutex> lk(c->mu);
+    for (;;) {
+        c->cv.wait(lk, [c] { return c->job_ready || c->quit; });
+        if (c->quit) return;
+        c->job_ready = false;
+        lk.unlock();
+        const int rc = run_host_batch(c, &c->job_batch, c->job_out);
+        if (rc != GBA_OK && rc != GBA_E_NOSPACE) {
+            // leave nothing of the failed batch running behind the caller's back
+            (void)hipSetDevice(c->device);
+            for (auto &sl : c->slot) { if (sl.s) (void)hipStreamSynchronize(sl.s); for (auto a : sl.aux) if (a) (void)hipStreamSynchronize(a); }
+            if (c->s_in) (void)hipStreamSynchronize(c->s_in);
+            if (c->s_out) (void)hipStreamSynchronize(c->s_out);
+        }
+        lk.lock();
+        c->job_rc = rc; c->job_done = true;
+        c->cv.notify_all();
+    }
+}
+
+int gba_submit(gba_ctx *c, const gba_batch *b, gba_results *out)
+{
+    if (!c || !b || !out) return GBA_E_INVALID;
+    if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
+    if (!batch_complete(b)) return GBA_E_INVALID;
+    if (b->n_pairs && (!out->pairs || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
+    if (b->n_pairs && !b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
+    std::unique_lock<std::mutex> lk(c->mu);
+    if (!c->worker.joinable()) {
+        try { c->worker = std::thread(worker_main, c); } catch (...) { return GBA_E_NOMEM; }
+    }
+    c->job_batch = *b; c->job_out = out;
+    c->job_ready = true; c->job_done = false;
     c->in_flight = true;
+    c->cv.notify_all();
     return GBA_OK;
 }
 
-int gba_wait(gba_ctx *c, gba_results *out)
+int gba_wait(gba_ctx *c)
 {
-    if (!c || !out) return GBA_E_INVALID;
+    if (!c) return GBA_E_INVALID;
     if (!c->in_flight) return GBA_E_STATE;
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->cv.wait(lk, [c] { return c->job_done; });
     c->in_flight = false;
-    const uint32_t n = c->flight_n;
-    out->blocks_needed = c->flight_needed;
-    if (n == 0) return GBA_OK;
-    if (!out->pairs) return GBA_E_INVALID;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(out->pairs, c->s_res.ptr, (size_t)n * sizeof(gba_pair_result), hipMemcpyDeviceToHost, c->stream));
-    const uint64_t fit = c->flight_needed <= out->blocks_capacity ? c->flight_needed : out->blocks_capacity;
-    if (fit && out->blocks)
-        HIPCHK(c, hipMemcpyAsync(out->blocks, c->s_out.ptr, (size_t)fit * sizeof(gba_block), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->flight_needed > out->blocks_capacity) {
-        for (uint32_t p = 0; p < n; p++) {
+    const int rc = c->job_rc;
+    if (rc == GBA_E_NOSPACE) {
+        // pairs whose blocks lie beyond the caller's arena
+        gba_results *out = c->job_out;
+        for (uint32_t p = 0; p < c->job_batch.n_pairs; p++) {
             gba_pair_result &R = out->pairs[p];
             if (R.status == GBA_PAIR_OK && R.blk_off + R.n_blk > out->blocks_capacity) R.status = GBA_PAIR_NOSPACE;
         }
-        return GBA_E_NOSPACE;
     }
-    return GBA_OK;
+    return rc;
+}
+
+void *gba_host_alloc(gba_ctx *c, uint64_t bytes)
+{
+    if (!c || c->in_flight) return nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes ? (size_t)bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { c->last_hip = (int)e; return nullptr; }
+    try { c->host_allocs.push_back(p); } catch (...) { (void)hipHostFree(p); return nullptr; }
+    return p;
+}
+
+void gba_host_free(gba_ctx *c, void *ptr)
+{
+    if (!c || !ptr) return;
+    for (size_t i = 0; i < c->host_allocs.size(); i++)
+        if (c->host_allocs[i] == ptr) {
+            (void)hipSetDevice(c->device);
+            (void)hipHostFree(ptr);
+            c->host_allocs.erase(c->host_allocs.begin() + (long)i);
+            return;
+        }
 }
 
 int gba_set_reference(gba_ctx *c, const uint8_t *ref, uint64_t len)

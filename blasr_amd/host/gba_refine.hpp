@@ -191,13 +191,13 @@ public:
         b.t_arena = (const uint8_t *)t_arena_.data(); b.t_off = t_off_.data(); b.t_len = t_len_.data();
         b.blocks = blocks_.data(); b.blk_off = b_off_.data(); b.n_blk = n_blk_.data();
         b.q_arena_bytes = q_arena_.size(); b.t_arena_bytes = t_arena_.size(); b.n_blocks_total = blocks_.size();
-        if ((rc = gba_submit(ctx_, &b)) != GBA_OK) return rc;
         uint64_t cap = n;
         for (uint32_t l : q_len_) cap += l;
         std::vector<gba_pair_result> pairs(n);
         std::vector<gba_block> out(cap);
         gba_results r{pairs.data(), out.data(), cap, 0};
-        if ((rc = gba_wait(ctx_, &r)) != GBA_OK) return rc;
+        if ((rc = gba_submit(ctx_, &b, &r)) != GBA_OK) return rc;     // returns at once: a caller with more reads
+        if ((rc = gba_wait(ctx_)) != GBA_OK) return rc;               // to prepare does that here, before waiting
         for (uint32_t i = 0; i < n; i++) {
             AlignmentCandidate &c = *cands_[i];
             const gba_pair_result &p = pairs[i];
@@ -278,11 +278,11 @@ inline int RefineGlobal(const std::string &read, std::vector<AlignmentCandidate 
         b.t_arena = (const uint8_t *)t_arena.data(); b.t_off = t_off.data(); b.t_len = t_len.data();
         b.blocks = &none; b.blk_off = b_off.data(); b.n_blk = n_blk.data();
         b.q_arena_bytes = read.size(); b.t_arena_bytes = t_arena.size(); b.n_blocks_total = 1;
-        if ((rc = gba_submit(ctx, &b)) != GBA_OK) return rc;
         std::vector<gba_pair_result> pairs(n);
         std::vector<gba_block> out(cap);
         gba_results r{pairs.data(), out.data(), cap, 0};
-        if ((rc = gba_wait(ctx, &r)) != GBA_OK) return rc;
+        if ((rc = gba_submit(ctx, &b, &r)) != GBA_OK) return rc;
+        if ((rc = gba_wait(ctx)) != GBA_OK) return rc;
         for (uint32_t i = 0; i < n; i++) {
             AlignmentCandidate &c = *cs[i];
             const gba_pair_result &p = pairs[i];

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GBA_VERSION 200   /* major*10000 + minor*100 + patch */
+#define GBA_VERSION 300   /* major*10000 + minor*100 + patch */
 
 /* return codes of the entry points */
 enum {
@@ -44,7 +44,9 @@ enum {
     GBA_PAIR_NOSPACE = 4,          /* blocks of this pair did not fit the caller's arena */
     GBA_PAIR_END_OUT_OF_BAND = 5,  /* k-band: |t_len - q_len| > k */
     GBA_PAIR_TOO_WIDE = 6,         /* a band row wider than the kernels support (linear, k-band: 1023 cells or a shift of 1023; affine: the same) */
-    GBA_PAIR_TOO_LONG = 7          /* more DP rows or columns than the kernels support (65535 rows, affine 32767; 2^20 columns) */
+    GBA_PAIR_TOO_LONG = 7          /* more DP rows or columns than the kernels support (65535 rows, affine 32767; 2^20 columns),
+                                      or rows x (128 + largest |substitution, insertion cost|) + columns x |deletion cost|
+                                      reaches 2^24 (affine 2^23): the scores would not fit the kernels' cell words */
 };
 
 enum { GBA_MODE_LINEAR = 0,   /* replaces GuidedAlign,       BlasrUtilsImpl.hpp:713-716, :727-730 */
@@ -175,14 +177,30 @@ void gba_destroy(gba_ctx *ctx);
 int gba_set_scoring(gba_ctx *ctx, const gba_scoring *s);
 
 /* Replaces the RefineAlignments loop over candidates (BlasrUtilsImpl.hpp:911-914)
- * for a whole batch.  gba_submit copies the host batch to the device and starts
- * it; gba_wait blocks, copies results into out->pairs / out->blocks (host
- * buffers) and returns GBA_OK or GBA_E_NOSPACE.  A batch with pairs must bring
- * every array except t_arena (NULL: windows of the reference) and t_rc:
- * GBA_E_INVALID otherwise; GBA_E_STATE without scoring, with a batch in flight,
- * or with a NULL t_arena and no reference. */
-int gba_submit(gba_ctx *ctx, const gba_batch *host_batch);
-int gba_wait(gba_ctx *ctx, gba_results *out);
+ * for a whole batch held in host memory.  gba_submit checks its arguments and
+ * returns at once: a worker thread of the ctx copies the batch to the device part
+ * by part, runs it and copies the results of each part into host_out->pairs /
+ * host_out->blocks while the next parts are still running, so that the copies in
+ * both directions overlap the kernels (and the caller's own work).  gba_wait
+ * blocks until host_out is complete (blocks_needed included) and returns GBA_OK,
+ * GBA_E_NOSPACE (pairs whose blocks did not fit have GBA_PAIR_NOSPACE) or the
+ * error the batch ran into.  The caller keeps the batch arrays, *host_out and its
+ * buffers alive and unread until gba_wait has returned.  Buffers from
+ * gba_host_alloc move at the full rate of the link; ordinary (pageable) memory
+ * works and is slower.
+ * A batch with pairs must bring every array except t_arena (NULL: windows of
+ * the reference) and t_rc: GBA_E_INVALID otherwise; GBA_E_STATE without scoring,
+ * with a batch in flight, or with a NULL t_arena and no reference. */
+int gba_submit(gba_ctx *ctx, const gba_batch *host_batch, gba_results *host_out);
+int gba_wait(gba_ctx *ctx);
+
+/* Page-locked host memory owned by the ctx, for batch arenas and result buffers:
+ * the pinned half of what the per-thread MappingBuffers (iblasr/MappingBuffers.hpp:20-49)
+ * becomes on this path, the device scratch of the ctx being the other half.
+ * NULL when the allocation fails or a batch is in flight.  Freed by gba_host_free
+ * or, whatever is left, by gba_destroy. */
+void *gba_host_alloc(gba_ctx *ctx, uint64_t bytes);
+void gba_host_free(gba_ctx *ctx, void *ptr);
 
 /* Same, for callers whose batch and result buffers already live in device
  * memory (all pointers in `dev_batch` and `dev_out` are device pointers).

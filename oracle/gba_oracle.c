@@ -29,11 +29,14 @@
  * qStart+g-1; a column is a target index t in [tStart-1, tEnd-1], tStart-1
  * being the boundary column.
  *
- * Build: gcc -O2 -shared -fPIC (see oracle/Makefile).
+ * Build: gcc -O3 -march=x86-64-v3 -shared -fPIC -pthread (see oracle/Makefile).
  */
+#define _POSIX_C_SOURCE 200809L
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define GBO_INF 0x3fffffff
 
@@ -86,6 +89,24 @@ int gbo_code(uint8_t c)
     }
 }
 
+/* Per-thread work space: the score / arrow matrices, guide rows and path of the pair in hand,
+ * grown to the largest pair seen and reused (the reference's per-thread MappingBuffers,
+ * /root/reference/iblasr/MappingBuffers.hpp:20-49, Blasr.cpp:771). */
+typedef struct { void *p; size_t cap; } gbo_buf;
+static _Thread_local gbo_buf tls_buf[8];
+static void *scratch(int which, size_t bytes)
+{
+    gbo_buf *b = &tls_buf[which];
+    if (bytes > b->cap) {
+        free(b->p);
+        b->cap = bytes + bytes / 4 + 4096;
+        b->p = malloc(b->cap);
+        if (!b->p) { b->cap = 0; return NULL; }
+    }
+    return b->p;
+}
+enum { BUF_GUIDE = 0, BUF_S, BUF_A, BUF_SI, BUF_SD, BUF_AI, BUF_AD, BUF_PATH };
+
 static int imin(int a, int b) { return a < b ? a : b; }
 static int iabs(int a) { return a < 0 ? -a : a; }
 
@@ -132,7 +153,7 @@ static guide_row *build_guide(const gbo_block *b, int nb, const gbo_params *P, i
     int qEnd = (int)(b[nb - 1].q_pos + b[nb - 1].length);
     int Q = qEnd - qStart;
     int B = imin(P->band, P->max_band);
-    guide_row *g = (guide_row *)malloc(sizeof(guide_row) * (size_t)(Q + 1));
+    guide_row *g = (guide_row *)scratch(BUF_GUIDE, sizeof(guide_row) * (size_t)(Q + 1));
     if (!g) return NULL;
     g[0].q = qStart - 1; g[0].t = tStart - 1; g[0].tPre = 0; g[0].tPost = B;
     int gi = 1;
@@ -160,7 +181,7 @@ static guide_row *build_guide(const gbo_block *b, int nb, const gbo_params *P, i
 static guide_row *build_kband(uint32_t q_len, uint32_t t_len, int k, int *n_rows)
 {
     int Q = (int)q_len;
-    guide_row *g = (guide_row *)malloc(sizeof(guide_row) * (size_t)(Q + 1));
+    guide_row *g = (guide_row *)scratch(BUF_GUIDE, sizeof(guide_row) * (size_t)(Q + 1));
     if (!g) return NULL;
     (void)t_len;
     for (int r = 0; r <= Q; r++) {
@@ -180,7 +201,7 @@ static void store_offsets(guide_row *g, int n, int64_t *ncells)
 }
 
 /* GetBufferIndex: index of cell (guide row r, target column t) or -1. */
-static int64_t cell_index(const guide_row *g, int n, int r, int t)
+static inline int64_t cell_index(const guide_row *g, int n, int r, int t)
 {
     if (r < 0 || r >= n) return -1;
     if (t <= g[r].t) { if (g[r].t - t <= g[r].tPre) return g[r].off - (g[r].t - t); return -1; }
@@ -206,13 +227,12 @@ int gbo_guide_rows(const gbo_block *b, int nb, uint32_t q_len, uint32_t t_len, c
     if (!g) return GBO_NOSPACE;
     store_offsets(g, n, ncells);
     *rows_out = n;
-    if (n > cap_rows) { free(g); return GBO_NOSPACE; }
+    if (n > cap_rows) return GBO_NOSPACE;
     for (int r = 0; r < n; r++) {
         int l = g[r].t - g[r].tPre - tStart + 1, h = g[r].t + g[r].tPost - tStart + 1;
         lo[r] = l < 0 ? 0 : l;
         hi[r] = h > T ? T : h;
     }
-    free(g);
     return GBO_OK;
 }
 
@@ -261,15 +281,18 @@ int gbo_align(const uint8_t *q, uint32_t q_len, const uint8_t *t, uint32_t t_len
     res->rows = (uint32_t)(qEnd - qStart); res->cols = (uint32_t)(tEnd - tStart);
 
     const int affine = (P->mode == GBO_MODE_AFFINE);
-    int32_t *S = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncells);
-    uint8_t *A = (uint8_t *)calloc((size_t)ncells, 1);
+    int32_t *S = (int32_t *)scratch(BUF_S, sizeof(int32_t) * (size_t)ncells);
+    uint8_t *A = (uint8_t *)scratch(BUF_A, (size_t)ncells);
     int32_t *SI = NULL, *SD = NULL; uint8_t *AI = NULL, *AD = NULL;
     if (affine) {
-        SI = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncells);
-        SD = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncells);
-        AI = (uint8_t *)calloc((size_t)ncells, 1);
-        AD = (uint8_t *)calloc((size_t)ncells, 1);
+        SI = (int32_t *)scratch(BUF_SI, sizeof(int32_t) * (size_t)ncells);
+        SD = (int32_t *)scratch(BUF_SD, sizeof(int32_t) * (size_t)ncells);
+        AI = (uint8_t *)scratch(BUF_AI, (size_t)ncells);
+        AD = (uint8_t *)scratch(BUF_AD, (size_t)ncells);
     }
+    if (!S || !A || (affine && (!SI || !SD || !AI || !AD))) { res->status = GBO_NOSPACE; return res->status; }
+    memset(A, 0, (size_t)ncells);
+    if (affine) { memset(AI, 0, (size_t)ncells); memset(AD, 0, (size_t)ncells); }
     for (int64_t i = 0; i < ncells; i++) { S[i] = GBO_INF; if (affine) { SI[i] = GBO_INF; SD[i] = GBO_INF; } }
 
     const int oe = P->affine_open + P->affine_extend, ex = P->affine_extend;
@@ -322,7 +345,7 @@ int gbo_align(const uint8_t *q, uint32_t q_len, const uint8_t *t, uint32_t t_len
         res->dp_score = S[endi];
         /* path is produced end->start; ops: 0 diag, 1 ins(up), 2 del(left) */
         size_t cap = (size_t)(qEnd - qStart) + (size_t)(tEnd - tStart) + 4, np = 0;
-        uint8_t *path = (uint8_t *)malloc(cap);
+        uint8_t *path = (uint8_t *)scratch(BUF_PATH, cap);
         int state = 0;      /* 0 match, 1 ins-gap, 2 del-gap */
         while (!(r == 0 && tt == tStart - 1)) {
             int64_t ci = cell_index(g, n, r, tt);
@@ -375,11 +398,9 @@ int gbo_align(const uint8_t *q, uint32_t q_len, const uint8_t *t, uint32_t t_len
             }
             if (nblk > blk_cap) status = GBO_NOSPACE;
         }
-        free(path);
     }
     res->status = status; res->n_blk = nblk; res->score = (int32_t)score2;
     res->n_match = nM; res->n_mismatch = nX; res->n_ins = nI; res->n_del = nD;
-    free(S); free(A); free(SI); free(SD); free(AI); free(AD); free(g);
     return status;
 }
 
@@ -422,5 +443,78 @@ int gbo_align_batch(const uint8_t *q_arena, const uint64_t *q_off, const uint32_
         gbo_align(q_arena + q_off[p], q_len[p], t_arena + t_off[p], t_len[p],
                   blocks + blk_off[p], (int)n_blk[p], P,
                   blocks_out + out_off[p], out_cap[p], &results[p]);
+    return GBO_OK;
+}
+
+/*
+ * The batch on all host cores, the way the reference runs it: `threads` workers, each with its
+ * own work space (the per-thread MappingBuffers of /root/reference/Blasr.cpp:771), pulling the
+ * next pair from a shared counter (the reader semaphore of
+ * /root/reference/iblasr/BlasrMiscsImpl.hpp:15-44 hands out reads the same way).  Stops handing
+ * out pairs after `seconds` (<= 0: never).  Used by bench.py's cpu_baseline leg.
+ */
+typedef struct {
+    const uint8_t *q_arena, *t_arena; const uint64_t *q_off, *t_off, *blk_off, *out_off;
+    const uint32_t *q_len, *t_len, *n_blk, *out_cap;
+    const gbo_block *blocks; const gbo_params *P;
+    gbo_result *results; gbo_block *blocks_out;
+    uint32_t first, count;
+    volatile uint32_t next;
+    double deadline;
+    uint64_t cells, pairs;
+    pthread_mutex_t mu;
+} mt_job;
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+
+static void *mt_worker(void *arg)
+{
+    mt_job *j = (mt_job *)arg;
+    uint64_t cells = 0, pairs = 0;
+    for (;;) {
+        if (j->deadline > 0 && now_s() >= j->deadline) break;
+        const uint32_t k = __atomic_fetch_add(&j->next, 1u, __ATOMIC_RELAXED);
+        if (k >= j->count) break;
+        const uint32_t p = j->first + k;
+        gbo_align(j->q_arena + j->q_off[p], j->q_len[p], j->t_arena + j->t_off[p], j->t_len[p],
+                  j->blocks + j->blk_off[p], (int)j->n_blk[p], j->P,
+                  j->blocks_out + j->out_off[p], j->out_cap[p], &j->results[p]);
+        if (j->results[p].status == GBO_OK) cells += (uint64_t)j->results[p].ncells;
+        pairs++;
+    }
+    for (int x = 0; x < 8; x++) { free(tls_buf[x].p); tls_buf[x].p = NULL; tls_buf[x].cap = 0; }
+    pthread_mutex_lock(&j->mu);
+    j->cells += cells; j->pairs += pairs;
+    pthread_mutex_unlock(&j->mu);
+    return NULL;
+}
+
+int gbo_align_batch_mt(const uint8_t *q_arena, const uint64_t *q_off, const uint32_t *q_len,
+                       const uint8_t *t_arena, const uint64_t *t_off, const uint32_t *t_len,
+                       const gbo_block *blocks, const uint64_t *blk_off, const uint32_t *n_blk,
+                       const gbo_params *P, uint32_t first, uint32_t count,
+                       gbo_result *results, gbo_block *blocks_out, const uint64_t *out_off, const uint32_t *out_cap,
+                       int threads, double seconds, uint64_t *pairs_done, uint64_t *cells_done, double *elapsed)
+{
+    mt_job j;
+    memset(&j, 0, sizeof(j));
+    j.q_arena = q_arena; j.t_arena = t_arena; j.q_off = q_off; j.t_off = t_off; j.blk_off = blk_off; j.out_off = out_off;
+    j.q_len = q_len; j.t_len = t_len; j.n_blk = n_blk; j.out_cap = out_cap; j.blocks = blocks; j.P = P;
+    j.results = results; j.blocks_out = blocks_out; j.first = first; j.count = count;
+    pthread_mutex_init(&j.mu, NULL);
+    if (threads < 1) threads = 1;
+    if (threads > 1024) threads = 1024;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    if (!th) return GBO_NOSPACE;
+    const double t0 = now_s();
+    j.deadline = seconds > 0 ? t0 + seconds : 0;
+    int started = 0;
+    for (int i = 0; i < threads; i++) if (pthread_create(&th[i], NULL, mt_worker, &j) == 0) th[started++] = th[i];
+    for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+    if (started == 0) mt_worker(&j);
+    *elapsed = now_s() - t0;
+    *pairs_done = j.pairs; *cells_done = j.cells;
+    free(th);
+    pthread_mutex_destroy(&j.mu);
     return GBO_OK;
 }

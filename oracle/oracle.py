@@ -70,6 +70,7 @@ def lib():
         _lib.gbo_guide_rows.restype = C.c_int
         _lib.gbo_full_dp_score.restype = C.c_int
         _lib.gbo_align_batch.restype = C.c_int
+        _lib.gbo_align_batch_mt.restype = C.c_int
     return _lib
 
 
@@ -177,3 +178,32 @@ def align_batch(batch, params, first=0, count=None, blk_cap_per_pair=None):
         k = min(int(results[i]["n_blk"]), int(caps[i]))
         blks.append(out[int(out_off[i]):int(out_off[i]) + k].copy())
     return results[first:first + count].copy(), blks
+
+
+def align_batch_mt(batch, params, threads, seconds=0.0, first=0, count=None):
+    """Pairs [first, first+count) on `threads` host threads (pthread workers inside the C
+    library, each with its own reusable work space, pulling pairs from a shared counter); stops
+    handing out pairs after `seconds` (0: runs them all).  Returns (results, blocks arena,
+    out_off, pairs_done, cells_done, elapsed_seconds); pairs are handed out in index order, so
+    pairs [first, first+pairs_done) are complete when no time limit cut the run."""
+    n = int(batch["n_pairs"])
+    count = n - first if count is None else count
+    q_len = np.ascontiguousarray(batch["q_len"], dtype=np.uint32)
+    caps = (q_len + 1).astype(np.uint32)
+    out_off = np.zeros(n, dtype=np.uint64)
+    out_off[1:] = np.cumsum(caps[:-1], dtype=np.uint64)
+    out = np.zeros(int(caps[first:first + count].sum()) + 1, dtype=BLOCK_DT)
+    out_off = out_off - out_off[first] if count else out_off
+    results = np.zeros(n, dtype=RESULT_DT)
+    arrs = {k: np.ascontiguousarray(batch[k]) for k in
+            ("q_arena", "q_off", "t_arena", "t_off", "t_len", "blocks", "blk_off", "n_blk")}
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    pairs_done, cells_done, elapsed = C.c_uint64(0), C.c_uint64(0), C.c_double(0)
+    lib().gbo_align_batch_mt(p(arrs["q_arena"]), p(arrs["q_off"]), p(q_len),
+                             p(arrs["t_arena"]), p(arrs["t_off"]), p(arrs["t_len"]),
+                             p(arrs["blocks"]), p(arrs["blk_off"]), p(arrs["n_blk"]),
+                             C.byref(params), C.c_uint32(first), C.c_uint32(count),
+                             p(results), p(out), p(out_off), p(caps),
+                             C.c_int(int(threads)), C.c_double(float(seconds)),
+                             C.byref(pairs_done), C.byref(cells_done), C.byref(elapsed))
+    return results, out, out_off, int(pairs_done.value), int(cells_done.value), float(elapsed.value)

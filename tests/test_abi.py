@@ -27,7 +27,7 @@ def test_exports_match_header():
 def test_version_and_strerror():
     from blasr_amd import _lib
     L = _lib.lib()
-    assert L.gba_version() == 200
+    assert L.gba_version() == 300
     assert L.gba_strerror(0) == b"ok"
     assert b"arena" in L.gba_strerror(_lib.E_NOSPACE)
     assert b"unknown" in L.gba_strerror(12345)
@@ -48,8 +48,8 @@ def test_argument_errors_without_gpu():
     L = _lib.lib()
     assert L.gba_create(None, None) == _lib.E_INVALID
     assert L.gba_set_scoring(None, None) == _lib.E_INVALID
-    assert L.gba_submit(None, None) == _lib.E_INVALID
-    assert L.gba_wait(None, None) == _lib.E_INVALID
+    assert L.gba_submit(None, None, None) == _lib.E_INVALID
+    assert L.gba_wait(None) == _lib.E_INVALID
     assert L.gba_get_timing(None, None) == _lib.E_INVALID
     L.gba_destroy(None)
 

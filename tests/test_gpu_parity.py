@@ -320,12 +320,16 @@ def test_incomplete_batch_is_refused(ctx, api, synth):
     from blasr_amd import _lib
     ctx.set_scoring(api.make_scoring())
     batch = synth.generate(4, read_len=100, seed=5)
+    pairs = np.zeros(4, dtype=_lib.PAIR_RESULT_DT)
+    blocks = np.zeros(500, dtype=_lib.BLOCK_DT)
+    r = _lib.Results(pairs.ctypes.data, blocks.ctypes.data, 500, 0)
     b, keep = api.make_batch_struct(batch)
     b.q_len = None
-    assert _lib.lib().gba_submit(ctx._h, C.byref(b)) == _lib.E_INVALID
+    assert _lib.lib().gba_submit(ctx._h, C.byref(b), C.byref(r)) == _lib.E_INVALID
     b, keep = api.make_batch_struct(batch)
     b.t_arena = None
-    assert _lib.lib().gba_submit(ctx._h, C.byref(b)) == _lib.E_STATE
+    assert _lib.lib().gba_submit(ctx._h, C.byref(b), C.byref(r)) == _lib.E_STATE
+    assert _lib.lib().gba_wait(ctx._h) == _lib.E_STATE       # nothing was submitted
     pairs, blocks, rc = ctx.refine_host(batch)          # the ctx is still usable
     assert rc == 0 and (pairs["status"] == 0).all()
 
@@ -540,6 +544,62 @@ def test_batches_in_parts(api, oracle, synth, monkeypatch, part):
         c2.close()
 
 
+def test_host_batches_pinned_async_and_out_of_order(api, oracle, synth, monkeypatch):
+    """gba_submit returns before the batch has run; batches and results in page-locked memory of
+    the ctx; arenas whose pairs are NOT laid out in pair order (each part of the batch then needs
+    stretches on both sides of what is on the device already); all in seven staggered parts."""
+    monkeypatch.setenv("GBA_PART_PAIRS", "128")
+    c2 = api.Context(0)
+    try:
+        n = 900
+        batch = synth.generate(n, read_len=1500, len_jitter=900, seed=505, decoy_every=6)
+        rng = np.random.default_rng(3)
+        perm = rng.permutation(n)
+        shuffled = dict(batch)
+        for k in ("q_off", "q_len", "t_off", "t_len", "blk_off", "n_blk"):
+            shuffled[k] = batch[k][perm].copy()
+        c2.set_scoring(api.make_scoring())
+        want, wblk, rc = c2.refine_host(batch)
+        assert rc == 0
+        util.compare_batch(oracle, batch, oracle.make_params(), want, wblk)
+        pb = c2.pinned_copy(shuffled)
+        pairs = c2.host_array(n, _lib_dt().PAIR_RESULT_DT)
+        blocks = c2.host_array(len(wblk) + 5, _lib_dt().BLOCK_DT)
+        for rep in range(3):
+            pairs[...] = 0
+            c2.submit_host(pb, pairs, blocks)
+            with pytest.raises(Exception):                 # one batch in flight per ctx
+                c2.submit_host(pb, pairs, blocks)
+            rc, needed = c2.wait_host()
+            assert rc == 0 and needed == len(wblk)
+            for f in util.FIELDS:
+                assert np.array_equal(pairs[f], want[f][perm]), f
+            for p in rng.integers(0, n, 40):
+                a = blocks[int(pairs["blk_off"][p]):int(pairs["blk_off"][p]) + int(pairs["n_blk"][p])]
+                o = perm[p]
+                b = wblk[int(want["blk_off"][o]):int(want["blk_off"][o]) + int(want["n_blk"][o])]
+                assert np.array_equal(a, b)
+        # an arena too small by half: the parts that fit are delivered, the rest is NOSPACE
+        small = c2.host_array(len(wblk) // 2, _lib_dt().BLOCK_DT)
+        c2.submit_host(pb, pairs, small)
+        rc, needed = c2.wait_host()
+        assert rc == -4 and needed == len(wblk)
+        fits = pairs["blk_off"].astype(np.int64) + pairs["n_blk"] <= len(small)
+        ok = want["status"][perm] == 0
+        assert (pairs["status"][ok & ~fits] == 4).all() and (pairs["status"][ok & fits] == 0).all()
+        end = int((pairs["blk_off"].astype(np.int64) + pairs["n_blk"])[ok & fits].max())
+        c2.submit_host(pb, pairs, blocks)
+        c2.wait_host()
+        assert np.array_equal(small[:end], blocks[:end])
+    finally:
+        c2.close()
+
+
+def _lib_dt():
+    from blasr_amd import _lib
+    return _lib
+
+
 def test_extra_rescoring_scorers(ctx, api, oracle, synth):
     """The path rescored with further scorers (the reference's probability score and edit distance,
     iblasr/BlasrUtilsImpl.hpp:120-151, :1056-1063).  One extra scorer repeats the stats scorer with
@@ -617,6 +677,28 @@ def test_maximum_rows(ctx, api, oracle, synth, mode, limit):
         kb = blocks[int(pairs[p]["blk_off"]):int(pairs[p]["blk_off"]) + int(pairs[p]["n_blk"])]
         assert np.array_equal(kb["q_pos"], blks["q_pos"]) and np.array_equal(kb["t_pos"], blks["t_pos"])
         assert np.array_equal(kb["length"], blks["length"])
+
+
+def test_score_range_of_the_cell_words(ctx, api, oracle, synth):
+    """At the largest costs the kernels accept, a pair is aligned (bit-exact) while its worst-case
+    score fits the cell words, and handed back TOO_LONG, not misreported, once it does not:
+    rows x (128 + 127) + columns x 127 against 2^24."""
+    from blasr_amd import _lib
+    kw = dict(mismatch=127, ins=127, dele=127, indel=9)
+    fits = _pair_with_rows(synth, 42_000, 33)            # 42 000 x 255 + ~40 600 x 127 < 2^24
+    over = _pair_with_rows(synth, 46_000, 34)
+    batch = util.make_batch([fits, over])
+    ctx.set_scoring(api.make_scoring(**kw))
+    pairs, blocks, rc = ctx.refine_host(batch)
+    assert rc == 0 and [int(x) for x in pairs["status"]] == [_lib.PAIR_OK, _lib.PAIR_TOO_LONG]
+    res, blks = oracle.align(fits[0], fits[1], fits[2], oracle.make_params(**kw))
+    for f in util.FIELDS:
+        assert int(res[f]) == int(pairs[0][f]), f
+    kb = blocks[:int(pairs[0]["n_blk"])]
+    assert np.array_equal(kb["q_pos"], blks["q_pos"]) and np.array_equal(kb["length"], blks["length"])
+    ctx.set_scoring(api.make_scoring())
+    pairs, _, rc = ctx.refine_host(batch)                # the same pairs at the default costs both fit
+    assert (pairs["status"] == 0).all()
 
 
 @pytest.mark.parametrize("mode", ["linear", "affine"])
