@@ -4,9 +4,17 @@
 One step = one pass of the whole hot path (guide rows, DP fill, traceback, block
 emission) over one batch of synthetic pairs that is already resident in HBM.
 Workload at N=1: BASELINE config 2 -- 10 kb reads, 15 % indel-heavy error, 4.6 Mb
-reference, linear gaps, band 10.  With N>1 every rank (one per GPU) owns an
-independent shard of the reads (sharded by read index, no data-path collective);
-the only communication is the timing barrier / max-reduce.
+reference, linear gaps, band 10 (--workload selects configs 3, 4, 5).  With N>1 there
+is ONE common synthetic read set; rank r (one per GPU) owns the reads with index
+= r (mod N) and all their candidates, generates exactly those, and after the timed
+steps writes their results at the reads' own places into one node-wide array
+(blasr_amd.shard.SharedMerge).  No data-path collective; the only communication is
+the timing barrier / max-reduce.  Per-GPU work is fixed (weak scaling).
+
+Beside the device-resident rate (`value`) the line carries, on rank 0 at N=1:
+  host_to_host  the same batch through gba_submit / gba_wait from and to page-locked
+                host memory (targets as windows of the resident reference)
+  cpu_baseline  the CPU oracle on all host cores over a bounded sample of the batch
 
 Prints ONE JSON line on rank 0.
 """
@@ -14,7 +22,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -22,47 +29,87 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# HBM bytes of one step's k_fill launches, from separate rocprofv3 --pmc passes of this command at the
-# default workload (profiles/r01_step8_hbm_pmc.txt): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction)
+# HBM bytes of one step's fill launches at the default workload, from separate rocprofv3 --pmc passes of
+# this command (profiles/, WRITE_SIZE + 2 x FETCH_SIZE: the gfx950 correction for streamed reads)
 MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 491520): 162394798 * 1024 + 2 * 15918231 * 1024}
-OPS_PER_CELL = 8            # algorithmic int32 ops per DP cell, linear gaps
-BYTES_PER_CELL = 0.25       # algorithmic traceback bytes per cell (2-bit arrows)
+OPS_PER_CELL = {"linear": 8, "affine": 18}         # algorithmic int32 ops per DP cell
+BYTES_PER_CELL = {"linear": 0.25, "affine": 0.75}  # algorithmic traceback bytes per cell
 VALU_PEAK_TOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz int32 lane-ops/s (= half the 157.3 TFLOP/s fp32 vector peak)
 HBM_PEAK_GBS = 8000.0
+DEFAULT_PAIRS = {"c2_10kb_linear": 491520, "c3_20kb_affine": 16384, "c4_chr20_bestn10": 163840,
+                 "c5_50kb_wide": 2048, "c1_ecoli_plumbing": 65536}
 
 
-def cpu_baseline(batch, seconds, threads):
-    """Oracle (C restatement, 'port') on host cores over a time-bounded sample of the same pairs."""
+def host_cores():
+    """Threads the CPU baseline may use: the CPUs this process may run on, capped by the
+    container's CPU quota when there is one (the affinity mask of a shared host shows every CPU of
+    the machine, the quota is what this job really gets)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit() and int(env) > 0:
+        n = min(n, int(env))            # the box exports its CPU share this way
+    return n
+
+
+def cpu_baseline(batch, scoring_kw, seconds, threads):
+    """Oracle (C restatement, 'port') on host cores over a time-bounded sample of the same pairs:
+    pthread workers with private reusable work space, pairs handed out from a shared counter."""
     from oracle import oracle
-    P = oracle.make_params()
-    n = int(batch["n_pairs"])
-    chunk = 4
-    nxt = [0]
-    cells = [0]
-    pairs_done = [0]
-    lock = threading.Lock()
-    deadline = time.time() + seconds
+    P = oracle.make_params(**scoring_kw)
+    _, _, _, pairs_done, cells, dt = oracle.align_batch_mt(batch, P, threads, seconds)
+    return cells / dt / 1e9, pairs_done, dt
 
-    def work():
-        while time.time() < deadline:
-            with lock:
-                first = nxt[0]
-                nxt[0] += chunk
-            if first >= n:
-                return
-            res, _ = oracle.align_batch(batch, P, first, min(chunk, n - first))
-            with lock:
-                cells[0] += int(res["ncells"][res["status"] == 0].sum())
-                pairs_done[0] += len(res)
 
-    t0 = time.time()
-    ths = [threading.Thread(target=work) for _ in range(threads)]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    dt = time.time() - t0
-    return cells[0] / dt / 1e9, pairs_done[0], dt
+def results_digest(pairs, blocks):
+    """A few sums that two runs of the same batch must agree on."""
+    return [int(pairs["score"].astype(np.int64).sum()), int(pairs["n_blk"].astype(np.int64).sum()),
+            int((pairs["status"] == 0).sum()), int(np.asarray(blocks).view(np.uint32).astype(np.uint64).sum())]
+
+
+def host_child(args):
+    """The host-to-host leg, in a process of its own: no PyTorch (the system's HIP runtime moves both
+    copy directions on the copy engines at once; the one bundled with PyTorch falls back to copy kernels
+    that take the GPU from the DP kernels), GPU_MAX_HW_QUEUES=16, and two contexts used in turn on the
+    GPU, each with its batch and result buffers in page-locked memory: what two of the reference's
+    worker threads sharing one GPU would do."""
+    from blasr_amd import api, synth, _lib
+    cfg = dict(synth.PRESETS[args.workload])
+    if args.band is not None:
+        cfg["band"] = args.band
+    affine = cfg["mode"] == "affine"
+    k = cfg.get("decoy_every", 0) or 1
+    n = args.pairs
+    ref = synth.reference(cfg["ref_len"], synth.REF_SEED, cfg.get("n_frac", 0.0))
+    host = synth.generate(n, share_reads=k > 1, ref=ref, **{a: b for a, b in cfg.items() if a != "ref"})
+    host = synth.as_windows(synth.compact_blocks(host))
+    pipe = api.HostPipeline(0, depth=args.host_contexts)
+    pipe.set_scoring(api.make_scoring(band=cfg["band"], max_band=args.max_band, mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR))
+    pipe.set_reference(ref)
+    bufs = []
+    for _ in range(args.host_contexts):
+        bufs.append((pipe.pinned_copy(host), pipe.host_array(n, _lib.PAIR_RESULT_DT), pipe.host_array(args.host_blocks, _lib.BLOCK_DT)))
+    for i in range(args.host_contexts):           # warm-up: every context once (its device buffers grow to size)
+        pipe.submit(*bufs[i]); rc, needed = pipe.wait()
+        if rc != 0:
+            raise SystemExit("host path rc=%d" % rc)
+    t0 = time.perf_counter()
+    pipe.submit(*bufs[0])
+    for i in range(args.host_steps):
+        if i + 1 < args.host_steps:
+            pipe.submit(*bufs[(i + 1) % args.host_contexts])
+        rc, needed = pipe.wait()
+    dt = (time.perf_counter() - t0) / args.host_steps
+    hb, pairs, blocks = bufs[(args.host_steps - 1) % args.host_contexts]
+    h2d = sum(hb[x].nbytes for x in ("q_arena", "blocks", "q_off", "t_off", "blk_off", "q_len", "t_len", "n_blk", "t_rc"))
+    print(json.dumps({"ms_per_step": dt * 1e3, "h2d_bytes": h2d, "d2h_bytes": n * _lib.PAIR_RESULT_DT.itemsize + needed * _lib.BLOCK_DT.itemsize,
+                      "cells": int(pairs["ncells"][pairs["status"] == 0].sum()), "digest": results_digest(pairs, blocks[:needed])}), flush=True)
+    pipe.close()
 
 
 def main():
@@ -70,17 +117,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=491520, help="pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=None, help="pairs per GPU per step (default: per workload)")
     ap.add_argument("--workload", default="c2_10kb_linear")
     ap.add_argument("--band", type=int, default=None, help="override the preset's band")
     ap.add_argument("--max-band", type=int, default=250, help="cap of the widened band in guide gaps (experiments)")
-    ap.add_argument("--streams", type=int, default=1, help="contexts per GPU, each on its own stream with pairs/streams pairs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-to-host measurement")
+    ap.add_argument("--host-steps", type=int, default=6)
+    ap.add_argument("--host-contexts", type=int, default=2)
+    ap.add_argument("--host-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--host-blocks", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.host_child:
+        return host_child(args)
 
     import torch
-    from blasr_amd import api, synth, _lib
+    from blasr_amd import api, shard, synth, _lib
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,49 +151,37 @@ def main():
     red = dev if world == 1 or dist.get_backend() == "nccl" else "cpu"      # where the timing reductions live
 
     cfg = dict(synth.PRESETS[args.workload])
-    # shard by read index: rank r owns the reads with global index = r (mod world); each rank
-    # draws its own shard from a rank-specific seed, per-GPU work is fixed (weak scaling)
-    cfg["seed"] = cfg["seed"] + 7919 * rank
-    S = max(1, args.streams)
-    n = args.pairs
-    per = [n // S + (1 if i < n % S else 0) for i in range(S)]
-    hosts, dbatches, outs, ctxs = [], [], [], []
+    n = args.pairs if args.pairs is not None else DEFAULT_PAIRS[args.workload]
     if args.band is not None:
         cfg["band"] = args.band
-    affine = cfg["mode"] == "affine"
-    scoring = api.make_scoring(band=cfg["band"], max_band=args.max_band, mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR)
-    for i in range(S):
-        c2 = dict(cfg); c2["seed"] = cfg["seed"] + 104729 * i
-        h = synth.generate(per[i], **c2)
-        hosts.append(h)
-        dbatches.append(api.to_device(h, dev))
-        cap = int(h["q_len"].astype(np.int64).sum() // 4) + per[i]      # ~1 block per 7.5 bases on this workload
-        outs.append((torch.zeros(per[i] * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device=dev),
-                     torch.zeros((cap, 3), dtype=torch.int32, device=dev)))
-        ctx = api.Context(local, timing=True)
-        ctx.set_scoring(scoring)
-        ctxs.append(ctx)
-    host = hosts[0]
+    mode = cfg["mode"]
+    affine = mode == "affine"
+    k = cfg.get("decoy_every", 0) or 1
+    n -= n % k                                   # whole reads
+    scoring_kw = dict(band=cfg["band"], max_band=args.max_band, mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR)
+    scoring = api.make_scoring(**scoring_kw)
+    # this rank's reads of the common set (index = rank mod world), all their candidates with them
+    ref = synth.reference(cfg["ref_len"], synth.REF_SEED, cfg.get("n_frac", 0.0))
+    host = synth.generate(n, shard=(rank, world), share_reads=k > 1, ref=ref, **{a: b for a, b in cfg.items() if a != "ref"})
+    dbatch = api.to_device(host, dev)
+    cap = int(host["q_len"].astype(np.int64).sum() // 4) + n      # ~1 block per 7.5 bases on these workloads
+    out_pairs = torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device=dev)
+    out_blocks = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
+    ctx = api.Context(local, timing=True)
+    ctx.set_scoring(scoring)
 
-    def run_steps(i, k, acc):
-        for _ in range(k):
-            rc, needed = ctxs[i].refine_device(dbatches[i], outs[i][0], outs[i][1])   # returns when the batch has completed
+    needed_dev = [0]
+
+    def run_steps(count):
+        fill = tb = 0.0
+        for _ in range(count):
+            rc, needed = ctx.refine_device(dbatch, out_pairs, out_blocks)   # returns when the batch has completed
             if rc != 0:
                 raise RuntimeError("refine_device rc=%d needed=%d" % (rc, needed))
-            tm = ctxs[i].timing()
-            acc[0] += tm["fill_ms"]; acc[1] += tm["traceback_ms"]
-
-    def run_all(k):
-        accs = [[0.0, 0.0] for _ in range(S)]
-        if S == 1:
-            run_steps(0, k, accs[0])
-        else:
-            ths = [threading.Thread(target=run_steps, args=(i, k, accs[i])) for i in range(S)]
-            for t in ths:
-                t.start()
-            for t in ths:
-                t.join()
-        return accs
+            needed_dev[0] = needed
+            tm = ctx.timing()
+            fill += tm["fill_ms"]; tb += tm["traceback_ms"]
+        return fill, tb
 
     def barrier():
         torch.cuda.synchronize()
@@ -148,39 +189,49 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_all(args.warmup)
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    accs = run_all(args.steps)
+    fill_ms, tb_ms = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    fill_ms = sum(a[0] for a in accs) / S
-    tb_ms = sum(a[1] for a in accs) / S
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=red)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # sanity: every pair aligned
-    n_ok = 0
-    cells_step = 0
-    rec_bytes = 0
-    for i in range(S):
-        res = outs[i][0].cpu().numpy().view(_lib.PAIR_RESULT_DT)
-        n_ok += int((res["status"] == 0).sum())
-        tm = ctxs[i].timing()
-        cells_step += int(tm["cells"])
-        rec_bytes += int(tm["record_bytes"])
+    res = out_pairs.cpu().numpy().view(_lib.PAIR_RESULT_DT)
+    tm = ctx.timing()
+    cells_step, rec_bytes = int(tm["cells"]), int(tm["record_bytes"])
+    n_ok = int((res["status"] == 0).sum())
     cells_all, ok_all = cells_step, n_ok
-    if world > 1:        # every rank has its own reads: sum the real counts
-        t = torch.tensor([cells_step, n_ok], dtype=torch.int64, device=red)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if world > 1:
+        # every rank's pair results go to their places in ONE array in input order; rank 0 counts there
+        name = "bench_%s" % os.environ.get("MASTER_PORT", "0")
+        merge = None
+        if rank == 0:
+            merge = shard.SharedMerge(name, n * world, 0, create=True)
+        dist.barrier()
+        if rank != 0:
+            merge = shard.SharedMerge(name, n * world, rank, create=False)
+        merge.write(np.asarray(host["pair_id"]), res)
+        dist.barrier()
+        if rank == 0:
+            allp = merge.pairs
+            ok_all = int((allp["status"] == 0).sum())
+            cells_all = int(allp["ncells"][allp["status"] == 0].sum())
+        dist.barrier()
+        merge.close()
+        t = torch.tensor([cells_all, ok_all], dtype=torch.int64, device=red)
+        dist.broadcast(t, 0)
         cells_all, ok_all = int(t[0].item()), int(t[1].item())
     total_cells = cells_all * args.steps
     gcups = total_cells / dt / 1e9
     fill_s = fill_ms / 1e3 / args.steps
-    ops_cell, bytes_cell = (18, 0.75) if affine else (OPS_PER_CELL, BYTES_PER_CELL)   # algorithmic work per cell
-    traffic = MEASURED_FILL_TRAFFIC.get((args.workload, n)) if S == 1 else None
+    ops_cell, bytes_cell = OPS_PER_CELL[mode], BYTES_PER_CELL[mode]
+    traffic = MEASURED_FILL_TRAFFIC.get((args.workload, n))
+    wide = tm["wide_pairs"] * 2 > n               # most pairs ran wave-per-pair: the bulk kernel is k_fill_wide
+    kernel = ("k_fill_wide_affine" if affine else "k_fill_wide") if wide else "k_fill<%s>" % ("true" if affine else "false")
     out = {
         "metric": "banded-DP GCUPS (guided banded alignment, refine stage)",
         "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world,
@@ -190,12 +241,12 @@ def main():
         "dtype": "int32", "data": "synthetic",
         "config": {"workload": args.workload, "pairs_per_gpu": n, "read_len": cfg["read_len"],
                    "error": "ins %.2f / del %.2f / sub %.2f" % (cfg["p_ins"], cfg["p_del"], cfg["p_sub"]),
-                   "streams": S, "band": cfg["band"], "gaps": cfg["mode"], "reference_len": cfg["ref_len"],
+                   "candidates_per_read": k, "band": cfg["band"], "gaps": mode, "reference_len": cfg["ref_len"],
                    "cells_per_step_per_gpu": cells_step, "pairs_ok": ok_all, "pairs_total": n * world,
-                   "parallelism": "reads sharded by index, %d rank(s), no collective" % world},
+                   "parallelism": "one common read set, reads i = rank (mod %d) per GPU, no collective, results merged in input order" % world},
         "aligned_reads_per_sec": round(n * args.steps * world / dt, 1),
         "roofline": {
-            "bound": "valu-int32", "kernel": "k_fill<%s>" % ("true" if affine else "false"),
+            "bound": "valu-int32", "kernel": kernel,
             "achieved": round(cells_step * ops_cell / fill_s / 1e12, 3), "peak": VALU_PEAK_TOPS,
             "unit": "Tops/s", "frac": round(cells_step * ops_cell / fill_s / 1e12 / VALU_PEAK_TOPS, 4),
             "ops_per_cell": ops_cell, "fill_ms": round(fill_s * 1e3, 3),     # bulk fill launches of a step, summed (HIP events)
@@ -203,18 +254,47 @@ def main():
             "traffic": traffic,
         },
         "roofline_hbm": {
-            "bound": "hbm", "kernel": "k_fill<false>",
+            "bound": "hbm", "kernel": kernel,
             "achieved": round(cells_step * bytes_cell / fill_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(cells_step * bytes_cell / fill_s / 1e9 / HBM_PEAK_GBS, 5),
             "record_bytes_written": rec_bytes, "traffic": traffic,
         },
         "traceback_ms": round(tb_ms / args.steps, 3),
     }
+
+    if rank == 0 and world == 1 and not args.no_host:
+        # The same batch from host memory to host memory (gba_submit / gba_wait), measured by a child
+        # process: see host_child().  This process gives the GPU's memory back first.
+        import subprocess
+        digest = results_digest(res, out_blocks[:needed_dev[0]].cpu().numpy())
+        del dbatch, out_blocks, out_pairs
+        ctx.close()
+        torch.cuda.empty_cache()
+        env = dict(os.environ, GBA_NO_TORCH="1", GPU_MAX_HW_QUEUES="16")
+        cmd = [sys.executable, os.path.abspath(__file__), "--host-child", "--workload", args.workload, "--pairs", str(n),
+               "--max-band", str(args.max_band), "--host-steps", str(args.host_steps), "--host-contexts", str(args.host_contexts),
+               "--host-blocks", str(needed_dev[0] + 16)] + (["--band", str(args.band)] if args.band is not None else [])
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        if p.returncode != 0:
+            out["host_to_host"] = {"error": (p.stderr or p.stdout)[-400:]}
+        else:
+            h = json.loads(p.stdout.strip().splitlines()[-1])
+            hg = h["cells"] / (h["ms_per_step"] / 1e3) / 1e9
+            out["host_to_host"] = {"gcups": round(hg, 2), "ms_per_step": round(h["ms_per_step"], 3),
+                                   "h2d_gb": round(h["h2d_bytes"] / 1e9, 3), "d2h_gb": round(h["d2h_bytes"] / 1e9, 3),
+                                   "frac_of_device_resident": round(hg / gcups, 3),
+                                   "same_results_as_device_path": h["digest"] == digest,
+                                   "how": "gba_submit / gba_wait, batch and results in page-locked memory (gba_host_alloc), targets = windows of "
+                                          "the resident reference, %d contexts used in turn on the GPU, %d batches back to back, "
+                                          "GPU_MAX_HW_QUEUES=16, child process on the system HIP runtime" % (args.host_contexts, args.host_steps)}
+
     if rank == 0 and world == 1 and not args.no_cpu:
-        threads = min(16, len(os.sched_getaffinity(0)))
-        v, done, secs = cpu_baseline(host, args.cpu_seconds, threads)
+        threads = host_cores()
+        v, done, secs = cpu_baseline(host, dict(scoring_kw, mode=1 if affine else 0), args.cpu_seconds, threads)
         out["cpu_baseline"] = {"value": round(v, 4), "unit": "GCUPS", "cores": threads, "kind": "port",
-                               "sample": "%d pairs of the same batch in %.1f s (oracle C restatement, not the BLASR binary)" % (done, secs)}
+                               "host_cpus_visible": len(os.sched_getaffinity(0)),
+                               "sample": "%d pairs of the same batch in %.1f s (oracle: C restatement built -O3 -march=x86-64-v3, "
+                                         "one thread per core with private work space; not the BLASR binary)" % (done, secs)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

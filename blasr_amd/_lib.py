@@ -90,10 +90,13 @@ def lib():
             raise RuntimeError("libgba.so not built: run `python -m blasr_amd.build` (hipcc, gfx950)")
         # One HIP runtime per process: PyTorch ships its own libamdhip64; importing it first makes
         # libgba.so bind to that copy, so tensors and gba contexts share one runtime.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        # (GBA_NO_TORCH=1: a process that only uses host buffers needs no PyTorch and runs on the
+        # system's HIP runtime.)
+        if not os.environ.get("GBA_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name in EXPORTS:
             getattr(L, name)          # AttributeError if a declared symbol is not exported

@@ -194,6 +194,51 @@ class Context:
         return rc, int(r.blocks_needed)
 
 
+class HostPipeline:
+    """Several contexts on ONE GPU used in turn, so that host-buffer batches overlap: batch k+1 is
+    submitted before batch k is waited for, its inputs travel while batch k computes, and batch k's
+    last results travel while batch k+1 starts.  This is what the reference's worker threads become
+    (one MappingBuffers = one context per thread, Blasr.cpp:771): with two or more of them per GPU
+    the link and the GPU are both kept busy.  Set GPU_MAX_HW_QUEUES=16 in the environment before the
+    HIP runtime starts (8 streams per context)."""
+
+    def __init__(self, device=0, depth=2):
+        self.ctxs = [Context(device) for _ in range(depth)]
+        self._sub = self._wait = 0
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+
+    def set_scoring(self, scoring):
+        for c in self.ctxs:
+            c.set_scoring(scoring)
+
+    def set_reference(self, ref):
+        for c in self.ctxs:
+            c.set_reference(ref)
+
+    def host_array(self, shape, dtype):
+        return self.ctxs[0].host_array(shape, dtype)
+
+    def pinned_copy(self, batch):
+        return self.ctxs[0].pinned_copy(batch)
+
+    def submit(self, batch, pairs, blocks):
+        if self._sub - self._wait >= len(self.ctxs):
+            raise GbaError(_lib.E_STATE)
+        self.ctxs[self._sub % len(self.ctxs)].submit_host(batch, pairs, blocks)
+        self._sub += 1
+
+    def wait(self):
+        """Waits for the oldest submitted batch.  Returns (rc, blocks_needed)."""
+        if self._wait >= self._sub:
+            raise GbaError(_lib.E_STATE)
+        r = self.ctxs[self._wait % len(self.ctxs)].wait_host()
+        self._wait += 1
+        return r
+
+
 def to_device(batch, device="cuda:0"):
     """Copy a host batch dict to torch CUDA tensors (bit patterns preserved)."""
     import torch

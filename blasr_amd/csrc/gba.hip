@@ -1789,6 +1789,7 @@ struct HostIO {
     const gba_batch *hb;          // the caller's batch (host pointers)
     gba_results *hout;            // the caller's result buffers (host pointers)
     gba_pair_result *d_res;       // device copy of the pair results
+    bool all_ahead = false;       // every part's inputs are queued at once (page-locked arenas, a hardware queue to spare)
     uint64_t need_before = 0;     // blocks of the parts emitted so far
     // byte / element ranges of the three arenas that are on the device already
     uint64_t have[3][2] = {{0, 0}, {0, 0}, {0, 0}};
@@ -1802,12 +1803,21 @@ int stage_part(gba_ctx *c, HostIO &io, uint32_t first, uint32_t cnt, hipEvent_t 
 {
     const gba_batch &b = *io.hb;
     hipStream_t st = c->s_in;
+    // The copies are the runtime's (copy engines): kernels that read or write host memory over the link
+    // themselves were measured and take far more from the DP kernels running beside them than they save.
+    auto move = [&](void *dst, const void *src_host, size_t bytes) -> int {
+        if (bytes) HIPCHK(c, hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, st));
+        return GBA_OK;
+    };
     struct { Buf *buf; const void *src; size_t esz; } per_pair[] = {
         {&c->s_qoff, b.q_off, 8}, {&c->s_toff, b.t_off, 8}, {&c->s_boff, b.blk_off, 8},
         {&c->s_qlen, b.q_len, 4}, {&c->s_tlen, b.t_len, 4}, {&c->s_nblk, b.n_blk, 4}, {&c->s_trc, b.t_rc, 1}};
-    for (auto &x : per_pair)
-        if (x.src) HIPCHK(c, hipMemcpyAsync((char *)x.buf->ptr + (size_t)first * x.esz, (const char *)x.src + (size_t)first * x.esz,
-                                            (size_t)cnt * x.esz, hipMemcpyHostToDevice, st));
+    for (int k = 0; k < 7; k++) {
+        auto &x = per_pair[k];
+        if (!x.src) continue;
+        int rc = move((char *)x.buf->ptr + (size_t)first * x.esz, (const char *)x.src + (size_t)first * x.esz, (size_t)cnt * x.esz);
+        if (rc) return rc;
+    }
     struct { int which; Buf *buf; const uint8_t *src; uint64_t extent; size_t esz; const uint64_t *off; const uint32_t *len; } arena[] = {
         {0, &c->s_q, b.q_arena, b.q_arena_bytes, 1, b.q_off, b.q_len},
         {1, &c->s_t, b.t_arena, b.t_arena_bytes, 1, b.t_off, b.t_len},
@@ -1828,9 +1838,11 @@ int stage_part(gba_ctx *c, HostIO &io, uint32_t first, uint32_t cnt, hipEvent_t 
             if (lo < have[0]) { pieces[np][0] = lo; pieces[np][1] = have[0]; np++; have[0] = lo; }
             if (hi > have[1]) { pieces[np][0] = have[1]; pieces[np][1] = hi; np++; have[1] = hi; }
         }
-        for (int k = 0; k < np; k++)
-            HIPCHK(c, hipMemcpyAsync((char *)a.buf->ptr + pieces[k][0] * a.esz, a.src + pieces[k][0] * a.esz,
-                                     (size_t)(pieces[k][1] - pieces[k][0]) * a.esz, hipMemcpyHostToDevice, st));
+        for (int k = 0; k < np; k++) {
+            int rc = move((char *)a.buf->ptr + pieces[k][0] * a.esz, a.src + pieces[k][0] * a.esz,
+                          (size_t)(pieces[k][1] - pieces[k][0]) * a.esz);
+            if (rc) return rc;
+        }
     }
     HIPCHK(c, hipEventRecord(done, st));
     return GBA_OK;
@@ -1933,7 +1945,11 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
             c->ev_in.push_back(e);
         }
         for (auto &sl : c->slot) sl.d2h_pending = false;
-        int rc = stage_part(c, *io, 0, n < per ? n : per, c->ev_in[0]); if (rc) return rc;
+        // all parts now, back to back beside the kernels, or one part ahead of the kernels
+        for (uint32_t h = 0; h < (io->all_ahead ? parts : 1u); h++) {
+            const uint32_t f = h * per;
+            int rc = stage_part(c, *io, f, n - f < per ? n - f : per, c->ev_in[h]); if (rc) return rc;
+        }
     }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
     HIPCHK(c, hipMemsetAsync(needed, 0, 8, s));
@@ -1952,7 +1968,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
         used[h % NSLOT] = true;
         rc = phase_guide(c, sl, d); if (rc) return rc;
         rc = phase_fill(c, sl, d, res + first, (uint32_t)NAUXS); if (rc) return rc;
-        if (io && h + 1 < parts) {       // the next part's inputs travel while this part runs
+        if (io && !io->all_ahead && h + 1 < parts) {       // the next part's inputs travel while this part runs
             const uint32_t nf = (h + 1) * per;
             rc = stage_part(c, *io, nf, n - nf < per ? n - nf : per, c->ev_in[h + 1]); if (rc) return rc;
         }
@@ -2042,8 +2058,6 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
             if (hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) == hipSuccess) c->fixed_base = (unsigned char *)sp;
             else (void)hipGetLastError();
         }
-        if (hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking) != hipSuccess) { rc = GBA_E_HIP; break; }
         if (const char *e = getenv("GBA_PART_PAIRS")) c->part_pairs = (uint32_t)strtoul(e, nullptr, 10);
         for (int h = 0; h < NSLOT && !rc; h++) {
             Slot &sl = c->slot[h];
@@ -2058,6 +2072,11 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
             for (int a = 0; a < NAUXS; a++)
                 if (hipStreamCreateWithFlags(&sl.aux[a], hipStreamNonBlocking) != hipSuccess) rc = GBA_E_HIP;
         }
+        // The copy streams come last: the runtime deals streams to its hardware queues (GPU_MAX_HW_QUEUES, 4 by
+        // default) in creation order, and which kernel streams share a queue decides how well the parts of a batch
+        // overlap.  With 8 queues every stream of a ctx has its own.
+        if (!rc && (hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking) != hipSuccess ||
+                    hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking) != hipSuccess)) rc = GBA_E_HIP;
     } while (0);
     if (rc) { gba_destroy(c); return rc; }
     *out = c;
@@ -2248,6 +2267,18 @@ static int run_host_batch(gba_ctx *c, const gba_batch *b, gba_results *out)
     dr.blocks_capacity = out->blocks_capacity; dr.blocks_needed = 0;
     HostIO io;
     io.hb = b; io.hout = out; io.d_res = dr.pairs;
+    // Page-locked arenas (gba_host_alloc, or pinned / registered by the caller) are copied by the copy
+    // engines without the calling thread; when the runtime also has a hardware queue to spare for the
+    // copy stream (GPU_MAX_HW_QUEUES of 8 or more; with the default 4 it shares one with a kernel stream,
+    // whose kernels would then wait for every copy queued before them), all parts are queued at once.
+    auto pinned = [](const void *p) {
+        hipPointerAttribute_t a;
+        memset(&a, 0, sizeof(a));
+        if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeHost;
+    };
+    const char *hq = getenv("GPU_MAX_HW_QUEUES");
+    io.all_ahead = hq && atoi(hq) >= 8 && pinned(b->q_arena) && pinned(b->blocks) && (!b->t_arena || pinned(b->t_arena));
     rc = run_device(c, &db, &dr, &io);
     out->blocks_needed = dr.blocks_needed;
     return rc;

@@ -26,7 +26,7 @@ class _Cfg(C.Structure):
                 ("p_sub", C.c_double), ("min_block", C.c_uint32), ("drop_frac", C.c_double),
                 ("seed", C.c_uint64), ("q_stride", C.c_uint32), ("t_stride", C.c_uint32),
                 ("blk_stride", C.c_uint32), ("decoy_every", C.c_uint32), ("len_jitter", C.c_uint32),
-                ("share_reads", C.c_uint32)]
+                ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32), ("share_reads", C.c_uint32)]
 
 
 def build(force=False):
@@ -87,13 +87,16 @@ PRESETS = {
 
 def generate(n_pairs, read_len=10000, p_ins=0.09, p_del=0.04, p_sub=0.02, min_block=11,
              drop_frac=0.10, seed=2000, ref_len=ECOLI_LEN, n_frac=0.0, decoy_every=0,
-             len_jitter=0, threads=8, ref=None, share_reads=False, **_ignored):
+             len_jitter=0, threads=8, ref=None, share_reads=False, shard=(0, 1), **_ignored):
     """Generate `n_pairs` pairs.  Returns a dict with q_arena, q_off, q_len, t_arena,
     t_off, t_len, blocks, blk_off, n_blk, n_pairs, plus win_start / win_rc (each target as a
     window of the reference: start on the forward strand, strand flag) and read_id (pairs with
     the same id are candidates of one read).  With decoy_every = k, pairs p with p % k != 0 are
     decoys: random loci with sparse guides; with share_reads they are further candidates of the
-    true pair's read (they view its query bytes), otherwise unrelated random reads."""
+    true pair's read (they view its query bytes), otherwise unrelated random reads.
+    shard = (rank, world): the pairs generated are those of the reads with index = rank (mod world)
+    of the common set that shard=(0, 1) generates, in order (a read = decoy_every consecutive pairs,
+    or one pair); read_id then holds the reads' indices in the common set."""
     lib = _load()
     if ref is None:
         ref = reference(ref_len, REF_SEED, n_frac)
@@ -101,7 +104,7 @@ def generate(n_pairs, read_len=10000, p_ins=0.09, p_del=0.04, p_sub=0.02, min_bl
     t_stride = int(read_len * 1.35) + 256
     blk_stride = read_len // min_block + 2
     cfg = _Cfg(read_len, p_ins, p_del, p_sub, min_block, drop_frac, seed, q_stride, t_stride,
-               blk_stride, decoy_every, len_jitter, 1 if share_reads else 0)
+               blk_stride, decoy_every, len_jitter, int(shard[0]), int(shard[1]), 1 if share_reads else 0)
     b = {
         "n_pairs": n_pairs,
         "q_arena": np.zeros(n_pairs * q_stride, dtype=np.uint8),
@@ -112,8 +115,13 @@ def generate(n_pairs, read_len=10000, p_ins=0.09, p_del=0.04, p_sub=0.02, min_bl
         "blk_off": np.zeros(n_pairs, dtype=np.uint64), "n_blk": np.zeros(n_pairs, dtype=np.uint32),
         "win_start": np.zeros(n_pairs, dtype=np.uint64), "win_rc": np.zeros(n_pairs, dtype=np.uint8),
     }
-    idx = np.arange(n_pairs, dtype=np.uint32)
-    b["read_id"] = idx - idx % decoy_every if (share_reads and decoy_every) else idx
+    idx = np.arange(n_pairs, dtype=np.int64)
+    k = decoy_every if (share_reads and decoy_every) else 1
+    kk = decoy_every if decoy_every else 1
+    # reads of this shard in the common set: groups of kk pairs are dealt round-robin over the ranks
+    common = ((idx // kk) * int(shard[1]) + int(shard[0])) * kk + idx % kk
+    b["pair_id"] = common                              # index of each pair in the common set
+    b["read_id"] = common // k
     p = lambda a: a.ctypes.data_as(C.c_void_p)
 
     def run(first, count):
@@ -141,6 +149,20 @@ def preset(name, n_pairs, **over):
     cfg = dict(PRESETS[name])
     cfg.update(over)
     return generate(n_pairs, **cfg), cfg
+
+
+def compact_blocks(batch):
+    """The same batch with its guide blocks packed end to end (the generator leaves every pair a
+    fixed stride of the block arena, most of it unused)."""
+    nb = np.asarray(batch["n_blk"], dtype=np.int64)
+    new_off = np.zeros(len(nb), np.int64)
+    new_off[1:] = np.cumsum(nb[:-1])
+    total = int(nb.sum())
+    src = np.repeat(np.asarray(batch["blk_off"], dtype=np.int64) - new_off, nb) + np.arange(total, dtype=np.int64)
+    out = dict(batch)
+    out["blocks"] = np.ascontiguousarray(batch["blocks"][src]) if total else np.zeros(1, BLOCK_DT)
+    out["blk_off"] = new_off.astype(np.uint64)
+    return out
 
 
 def as_windows(batch):

@@ -5,9 +5,10 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
-from blasr_amd import shard
+from blasr_amd import _lib, shard
 
 
 def test_shard_indices_partition():
@@ -15,8 +16,36 @@ def test_shard_indices_partition():
         for world in (1, 2, 3, 8):
             seen = sorted(i for r in range(world) for i in shard.shard_indices(n, r, world))
             assert seen == list(range(n))
-    per_rank = [[("r", i) for i in shard.shard_indices(10, r, 3)] for r in range(3)]
-    assert shard.merge_in_input_order(10, per_rank) == [("r", i) for i in range(10)]
+
+
+def _oracle_results(oracle, batch):
+    """What a context returns for the batch, computed by the oracle: pairs with packed blocks."""
+    res, blks = oracle.align_batch(batch, oracle.make_params())
+    n = len(res)
+    pairs = np.zeros(n, dtype=_lib.PAIR_RESULT_DT)
+    for f in ("status", "dp_score", "score", "q_pos", "t_pos", "n_blk", "n_match", "n_mismatch", "n_ins", "n_del", "rows", "cols", "ncells"):
+        pairs[f] = res[f]
+    nb = np.where(pairs["status"] == 0, pairs["n_blk"], 0).astype(np.int64)
+    off = np.zeros(n, np.int64)
+    off[1:] = np.cumsum(nb[:-1])
+    pairs["blk_off"] = off
+    blocks = np.concatenate([b for b, r in zip(blks, res) if r["status"] == 0 and len(b)] or [np.zeros(0, _lib.BLOCK_DT)])
+    return pairs, blocks
+
+
+def test_split_and_merge_keep_reads_together(oracle, synth):
+    batch = synth.generate(45, read_len=300, seed=21, decoy_every=5, share_reads=True, ref_len=150_000)
+    want_p, want_b = _oracle_results(oracle, batch)
+    for world in (1, 2, 4):
+        idxs = shard.split_by_read(batch, world)
+        assert sorted(np.concatenate(idxs).tolist()) == list(range(45))
+        parts = []
+        for r, idx in enumerate(idxs):
+            assert len(set((batch["read_id"][idx] % world).tolist())) <= 1            # whole reads, all on rank r
+            p, b = _oracle_results(oracle, shard.sub_batch(batch, idx))
+            parts.append((idx, p, b))
+        mp_, mb_ = shard.merge_in_input_order(45, parts)
+        assert mp_.tobytes() == want_p.tobytes() and mb_.tobytes() == want_b.tobytes()
 
 
 def _free_port():
@@ -27,45 +56,56 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_reads, q):
+N_READS, CANDS = 9, 4
+
+
+def _worker(rank, world, port, name, tmpdir):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from blasr_amd import synth
     from oracle import oracle
-    batch = synth.generate(n_reads, read_len=400, seed=9, threads=1)
-    P = oracle.make_params()
-    local = []
-    for i in shard.shard_indices(n_reads, rank, world):
-        qq, tt, blk = synth.pair(batch, i)
-        r, b = oracle.align(qq, tt, blk, P)
-        local.append((i, r["score"], r["n_blk"]))
-    merged = shard.gather_results(local, n_reads)
+    # this rank's reads of the common set, generated directly (nobody materialises the others')
+    n_local = len(shard.shard_indices(N_READS, rank, world)) * CANDS
+    local = synth.generate(n_local, read_len=400, seed=9, threads=1, decoy_every=CANDS, share_reads=True,
+                           ref_len=150_000, shard=(rank, world))
+    pairs, blocks = _oracle_results(oracle, local)
+    idx = np.asarray(local["pair_id"])
+    m = shard.SharedMerge(name, N_READS * CANDS, rank, create=False, directory=tmpdir)
+    m.write(idx, pairs)
+    dist.barrier()                                   # timing only: everybody's pairs are in place
+    off, total = m.block_offsets()
     if rank == 0:
-        q.put(merged)
+        m.open_blocks(total, create=True)
     dist.barrier()
+    if rank != 0:
+        m.open_blocks(total, create=False)
+    m.write_blocks(idx, pairs, blocks, off)
+    dist.barrier()
+    m.close()
     dist.destroy_process_group()
 
 
-def test_two_ranks_merge_in_input_order():
-    from blasr_amd import synth
-    from oracle import oracle
-    synth.build(); oracle.build()
-    n_reads, world, port = 13, 2, _free_port()
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_merge_into_one_array_in_input_order(oracle, synth, tmp_path, world):
+    """One process per rank, each with the reads i = rank (mod world) of one common read set and all
+    their candidates: the merged result is byte-identical to what one rank computes for the set."""
+    name = "t%d" % os.getpid()
+    owner = shard.SharedMerge(name, N_READS * CANDS, 0, create=True, directory=str(tmp_path))
+    port = _free_port()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_reads, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, str(tmp_path))) for r in range(world)]
     for p in procs:
         p.start()
-    merged = q.get(timeout=120)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=180)
         assert p.exitcode == 0
-    assert [m[0] for m in merged] == list(range(n_reads))
-    batch = synth.generate(n_reads, read_len=400, seed=9, threads=1)
-    P = oracle.make_params()
-    for i in range(n_reads):
-        qq, tt, blk = synth.pair(batch, i)
-        r, _ = oracle.align(qq, tt, blk, P)
-        assert merged[i] == (i, r["score"], r["n_blk"])
+    full = synth.generate(N_READS * CANDS, read_len=400, seed=9, threads=1, decoy_every=CANDS, share_reads=True, ref_len=150_000)
+    want_p, want_b = _oracle_results(oracle, full)
+    got_p = np.array(owner.pairs)
+    owner.open_blocks(len(want_b), create=False)
+    got_b = np.array(owner.blocks[:len(want_b)])
+    owner.close()
+    assert got_p.tobytes() == want_p.tobytes()
+    assert got_b.tobytes() == want_b.tobytes()
