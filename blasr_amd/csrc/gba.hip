@@ -51,8 +51,12 @@ constexpr uint32_t MAX_ROWS_AFFINE = 32767;  // affine words carry one more tag 
 constexpr uint32_t MAX_COLS = 1u << 20;
 // Classes of the lane-per-pair fill kernel: a pair's class is the smallest LDS row buffer
 // (32 << class slots) that holds its widest "shift + width".  Each non-empty class is one launch.
-constexpr int NCLS = 5;                      // lane-per-pair classes of 32, 64, 128, 256 slots, then the wave-per-pair class
-constexpr int CLS_WIDE = NCLS - 1;           // pairs too wide for the lane classes in use: k_fill_wide / k_fill_wide_affine
+constexpr int NCLS = 5;                      // lane-per-pair classes of 32, 64, 128 slots, then the two wave-per-pair classes
+constexpr int CLS_WIDE = NCLS - 1;           // pairs too wide for everything else: k_fill_wide<4> / k_fill_wide_affine<false>
+constexpr int CLS_WNARROW = NCLS - 2;        // wave-per-pair with a small ring (shift + width <= WN_SPAN): pairs a little too wide for
+                                             // the lane classes, and ALL pairs of a batch too small to fill the GPU one lane per pair
+constexpr uint32_t WN_SPAN = 124;
+static_assert(CLS_WNARROW == 3, "lane classes are 0..2");
 constexpr int LANE_CLS_LINEAR = 3;           // linear gaps: lane classes of 32, 64, 128 slots, anything wider is cheaper wave-per-pair
                                              // (a 96-slot class was measured: the batch gets slower, not faster)
 constexpr int LANE_CLS_AFFINE = 3;           // affine gaps: the same (two rings per wave)
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(SCAN_T) void k_plan(Dev d, int ncls, int has_wide)
         if (d.status[p] == GBA_PAIR_OK) {
             const uint32_t s = d.span[p];
             for (int k = ncls - 1; k >= 0; k--) if (s + SPAN_MARGIN <= cls_slots(k)) c = (uint32_t)k;
-            if (c == NCLS && has_wide) c = CLS_WIDE;
+            if (c == NCLS && has_wide) c = s <= WN_SPAN ? CLS_WNARROW : CLS_WIDE;
             if (c == NCLS) d.status[p] = GBA_PAIR_TOO_WIDE;
             else atomicAdd(&cnt[c], 1u);
         }
@@ -529,11 +533,11 @@ __global__ __launch_bounds__(SCAN_T) void k_plan(Dev d, int ncls, int has_wide)
         // goes wave-per-pair (a lone lane-per-pair wave lasts as long as a full launch); then the
         // narrowest classes merge upwards until two are left.
         for (int c = 0; c <= NCLS; c++) cmap[c] = (uint32_t)c;
-        auto nonempty = [&]() { int k = 0; for (int c = 0; c < CLS_WIDE; c++) k += cnt[c] ? 1 : 0; return k; };
+        auto nonempty = [&]() { int k = 0; for (int c = 0; c < CLS_WNARROW; c++) k += cnt[c] ? 1 : 0; return k; };
         if (has_wide && nonempty() > 2) {
-            int top = CLS_WIDE - 1;
+            int top = CLS_WNARROW - 1;
             while (!cnt[top]) top--;
-            if (cnt[top] <= 1024u) { cnt[CLS_WIDE] += cnt[top]; cnt[top] = 0; cmap[top] = CLS_WIDE; }
+            if (cnt[top] <= 1024u) { cnt[CLS_WNARROW] += cnt[top]; cnt[top] = 0; cmap[top] = CLS_WNARROW; }
         }
         while (nonempty() > 2) {
             int lo = 0;
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(SCAN_T) void k_plan(Dev d, int ncls, int has_wide)
             int up = lo + 1;
             while (!cnt[up]) up++;
             cnt[up] += cnt[lo]; cnt[lo] = 0;
-            for (int c = 0; c < CLS_WIDE; c++) if (cmap[c] == (uint32_t)lo) cmap[c] = (uint32_t)up;
+            for (int c = 0; c < CLS_WNARROW; c++) if (cmap[c] == (uint32_t)lo) cmap[c] = (uint32_t)up;
         }
         uint32_t a = 0;
         for (int c = 0; c < NCLS; c++) { base[c] = a; a += cnt[c]; }
@@ -894,9 +898,14 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
 // compared word) and records are exactly those of k_fill.
 //
 // Guide words are staged through an LDS ring of the wave, refilled 64 words at a time.
+// Two instances: NB = 4 chunks of 64 columns in flight and a ring for rows of any width the guide
+// stream can describe (the widest class), and NB = 1 with a small ring for shift + width <= WN_SPAN
+// (2.4 KB of LDS per wave instead of 11.5 KB: eight waves per SIMD instead of three; this is the
+// instance that takes whole batches too small to fill the GPU one lane per pair).
 constexpr int WIDE_NB = 4;                   // chunks of 64 columns in flight
 constexpr int WIDE_RING = 2048 + 64 * WIDE_NB;          // shift + width <= 2046, lanes run up to 63 columns past the row end
 constexpr int WIDE_SBUF = 512;                // guide words buffered per wave (a row has at most 1 + 128)
+constexpr int WN_RING = 192, WN_SBUF = 128;   // the small instance: WN_SPAN + 63 slots; a row has at most 1 + 16 words
 
 __device__ __forceinline__ int32_t wave_scan_min(int32_t v, int32_t identity)
 {
@@ -909,16 +918,19 @@ __device__ __forceinline__ int32_t wave_scan_min(int32_t v, int32_t identity)
     return v;
 }
 
-__global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc)
+template <int NB>
+__global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t cls)
 {
-    __shared__ uint32_t ring[WIDE_RING];
+    constexpr int WIDE_NB = NB;
+    constexpr int WIDE_SBUF = NB == 1 ? WN_SBUF : ::WIDE_SBUF;
+    __shared__ uint32_t ring[NB == 1 ? WN_RING : WIDE_RING];
     __shared__ uint32_t sbuf[WIDE_SBUF];
     __shared__ uint32_t tab[LDS_TAB];
     constexpr uint32_t TAGS = 31u;
     constexpr int32_t BIG = 0x60000000;                 // identity of the prefix minimum (no overflow when offsets are added)
     const int lane = threadIdx.x;
     if (lane < 10) tab[lane] = fc.mrow[lane];
-    const uint32_t p = d.order[d.plan->cls_base[CLS_WIDE] + blockIdx.x];
+    const uint32_t p = d.order[d.plan->cls_base[cls] + blockIdx.x];
     const uint32_t Q = d.Q[p];
     const uint32_t fslot = d.T[p] - d.lo_last[p];       // slot of the end cell (Q, T) in the last row
     const uint32_t *st = d.stream + d.word_off[p];
@@ -930,8 +942,8 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc)
     uint32_t W = 0, Wp = 0, dsh = 0, roff = 0;
     __syncthreads();
     for (uint32_t r = 0; r <= Q; r++) {
-        // keep at least 256 guide words buffered (or everything that is left)
-        while (sload - spos < 256u && sload < wcap) {
+        // keep at least half the buffer's worth of guide words buffered (or everything that is left)
+        while (sload - spos < (uint32_t)WIDE_SBUF / 2 && sload < wcap) {
             const uint32_t x = sload + lane;
             const uint32_t v = x < wcap ? st[x] : 0u;
             sbuf[x & (WIDE_SBUF - 1)] = v;
@@ -1023,17 +1035,19 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc)
 // Both are prefix minima of a(j) - j * slope for the two slopes P and E: two wave scans with scalar
 // carries between chunks.  The words of the left neighbour are then rebuilt from x and y, and the
 // arrow, the gap bits and the tie-breaks are decided per cell exactly as in k_fill<true>.
-__global__ __launch_bounds__(64) void k_fill_wide_affine(Dev d, FillConst fc)
+template <bool NARROW>
+__global__ __launch_bounds__(64) void k_fill_wide_affine(Dev d, FillConst fc, uint32_t cls)
 {
-    __shared__ uint32_t ringM[WIDE_RING];
-    __shared__ uint32_t ringI[WIDE_RING];
+    constexpr int WIDE_SBUF = NARROW ? WN_SBUF : ::WIDE_SBUF;
+    __shared__ uint32_t ringM[NARROW ? WN_RING : WIDE_RING];
+    __shared__ uint32_t ringI[NARROW ? WN_RING : WIDE_RING];
     __shared__ uint32_t sbuf[WIDE_SBUF];
     __shared__ uint32_t tab[LDS_TAB];
     constexpr uint32_t TAGS = 63u;
     constexpr int32_t BIG = 0x60000000;
     const int lane = threadIdx.x;
     if (lane < 10) tab[lane] = fc.mrow[lane];
-    const uint32_t p = d.order[d.plan->cls_base[CLS_WIDE] + blockIdx.x];
+    const uint32_t p = d.order[d.plan->cls_base[cls] + blockIdx.x];
     const uint32_t Q = d.Q[p];
     const uint32_t fslot = d.T[p] - d.lo_last[p];
     const uint32_t *st = d.stream + d.word_off[p];
@@ -1047,7 +1061,7 @@ __global__ __launch_bounds__(64) void k_fill_wide_affine(Dev d, FillConst fc)
     uint32_t W = 0, Wp = 0, dsh = 0, roff = 0;
     __syncthreads();
     for (uint32_t r = 0; r <= Q; r++) {
-        while (sload - spos < 256u && sload < wcap) {
+        while (sload - spos < (uint32_t)WIDE_SBUF / 2 && sload < wcap) {
             const uint32_t x = sload + lane;
             const uint32_t v = x < wcap ? st[x] : 0u;
             sbuf[x & (WIDE_SBUF - 1)] = v;
@@ -1310,7 +1324,7 @@ constexpr int WT_WIN = 4096;      // record dwords per refill
 constexpr int WT_TC = 2048;       // target codes (bytes) per refill
 
 template <bool AFF>
-__global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_pair_result *res)
+__global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_pair_result *res, uint32_t cls)
 {
     constexpr uint32_t CSHIFT = AFF ? 2u : 4u, CMASK = AFF ? 3u : 15u, BITS = AFF ? 8u : 2u;
     __shared__ int32_t sub[25 * (1 + GBA_MAX_EXTRA)];
@@ -1323,7 +1337,7 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
     const int nx = tc_.n_extra;
     int32_t xs0 = 0, xs1 = 0, xp0 = 0, xp1 = 0;         // extra scorers: sums, and the lookups of the last diagonal move
     const int lane = threadIdx.x;
-    const uint32_t p = d.order[d.plan->cls_base[CLS_WIDE] + blockIdx.x];
+    const uint32_t p = d.order[d.plan->cls_base[cls] + blockIdx.x];
     if (d.status[p] != GBA_PAIR_OK) return;             // fill found the end cell unreachable
     const uint32_t Q = d.Q[p], T = d.T[p];
     const uint32_t *rec = d.rec + d.rec_off[p];
@@ -1548,6 +1562,7 @@ struct gba_ctx {
     gba_scoring sc;
     FillConst fc;
     TbConst tbc;
+    uint32_t wave_pairs = 20480, wave_pairs_affine = 57344;   // batches (parts) smaller than this run wave-per-pair (env GBA_WAVE_PAIRS, GBA_WAVE_PAIRS_AFFINE)
     uint32_t score_a = 0, score_b = 0;   // largest cost of a row move / of a move along a row (k_meta's score-range check)
     uint32_t part_pairs = 122880;    // a batch of more than ~1.07 x this many pairs is run in staggered parts of about this
                                      // size (env GBA_PART_PAIRS, 0 = never).  Two lane-per-pair waves per SIMD is what the GPU
@@ -1674,7 +1689,13 @@ int phase_guide(gba_ctx *c, Slot &sl, Dev &d)
     d.blk_scratch = (gba_block *)sl.b_blk.ptr;
     hipLaunchKernelGGL(k_pack, dim3(d.n), dim3(256), 0, sl.s, d);
     hipLaunchKernelGGL(k_guide, dim3(d.n), dim3(64), 0, sl.s, d, sc.mode, sc.band, sc.max_band, sc.kband_k);
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(SCAN_T), 0, sl.s, d, sc.mode == GBA_MODE_AFFINE ? LANE_CLS_AFFINE : LANE_CLS_LINEAR, 1);
+    // A lane-per-pair launch lasts as long as its longest pair whatever the number of pairs, and needs
+    // two waves on every SIMD (131 072 pairs) to fill the GPU; the wave-per-pair kernels take several
+    // times the instructions per cell but fill the GPU from a few thousand pairs on.  Below wave_pairs
+    // pairs the whole batch runs one wave per pair.
+    const bool affine = sc.mode == GBA_MODE_AFFINE;
+    const int lane_classes = d.n < (affine ? c->wave_pairs_affine : c->wave_pairs) ? 0 : (affine ? LANE_CLS_AFFINE : LANE_CLS_LINEAR);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(SCAN_T), 0, sl.s, d, lane_classes, 1);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(sl.h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, sl.s));
     return GBA_OK;
@@ -1699,21 +1720,22 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
     hipLaunchKernelGGL(k_results_init, dim3((d.n + 255) / 256), dim3(256), 0, s, d, res);
     HIPCHK(c, hipEventRecord(sl.t_fill0, s));
     const bool aff = sc.mode == GBA_MODE_AFFINE;
-    auto launch_tb = [&](int k, hipStream_t st) {          // the wave-per-pair class
+    auto launch_tb = [&](int k, hipStream_t st) {          // a wave-per-pair class
         const uint32_t cnt = pl.cls_count[k];
-        if (aff) hipLaunchKernelGGL(k_traceback_wide<true>, dim3(cnt), dim3(64), 0, st, d, c->tbc, res);
-        else hipLaunchKernelGGL(k_traceback_wide<false>, dim3(cnt), dim3(64), 0, st, d, c->tbc, res);
+        if (aff) hipLaunchKernelGGL(k_traceback_wide<true>, dim3(cnt), dim3(64), 0, st, d, c->tbc, res, (uint32_t)k);
+        else hipLaunchKernelGGL(k_traceback_wide<false>, dim3(cnt), dim3(64), 0, st, d, c->tbc, res, (uint32_t)k);
     };
-    auto launch_tb_lanes = [&](hipStream_t st) {           // all lane classes: order[0 .. first wave-per-pair pair)
+    // The lane-per-pair traceback serves the lane classes AND the narrow wave-per-pair class (order[0 .. first pair of the
+    // widest class)): a wave that walks one pair on the scalar unit pays off for rows of hundreds of cells, not for these.
+    auto launch_tb_lanes = [&](hipStream_t st) {
         const uint32_t cnt = pl.cls_base[CLS_WIDE];
         const dim3 grid((cnt + TB_LANES - 1) / TB_LANES), block(TB_LANES);
         if (aff) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, st, d, c->tbc, res, 0u, cnt);
         else hipLaunchKernelGGL(k_traceback<false>, grid, block, 0, st, d, c->tbc, res, 0u, cnt);
     };
     HIPCHK(c, hipEventRecord(sl.ev_fork, s));
-    bool used[NAUXS] = {};
-    int nonempty = 0, wide_aux = -1;
-    bool wide_main = false;
+    bool used[NAUXS] = {}, wave_on_aux[NAUXS] = {}, wave_on_main[NCLS] = {};
+    int nonempty = 0;
     for (int k = 0; k < NCLS; k++) nonempty += pl.cls_count[k] ? 1 : 0;
     uint32_t n_aux = nonempty > 0 ? (uint32_t)nonempty - 1u : 0u;       // the narrowest class stays on the main stream
     if (n_aux > max_aux) n_aux = max_aux;
@@ -1722,35 +1744,40 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
         const uint32_t cnt = pl.cls_count[k];
         if (!cnt) continue;
         hipStream_t st = s;
-        const bool aux = sl.launches < n_aux;
+        const bool aux = sl.launches < n_aux, wave = k >= CLS_WNARROW;
+        const int a = (int)sl.launches;
         if (aux) {
-            const int a = (int)sl.launches;
             st = sl.aux[a];
             HIPCHK(c, hipStreamWaitEvent(st, sl.ev_fork, 0));
             used[a] = true;
         }
-        if (k == CLS_WIDE) {
-            if (aff) hipLaunchKernelGGL(k_fill_wide_affine, dim3(cnt), dim3(64), 0, st, d, c->fc);
-            else hipLaunchKernelGGL(k_fill_wide, dim3(cnt), dim3(64), 0, st, d, c->fc);
+        if (wave) {
+            if (k == CLS_WIDE) {
+                if (aff) hipLaunchKernelGGL(k_fill_wide_affine<false>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+                else hipLaunchKernelGGL(k_fill_wide<4>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+            } else {
+                if (aff) hipLaunchKernelGGL(k_fill_wide_affine<true>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+                else hipLaunchKernelGGL(k_fill_wide<1>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+            }
             HIPCHK(c, hipGetLastError());
         } else {
             int rc = launch_fill(c, d, (uint32_t)k, cnt, st);
             if (rc) return rc;
         }
         if (aux) {
-            if (k == CLS_WIDE) launch_tb(k, st);
-            HIPCHK(c, hipEventRecord(sl.ev_join[sl.launches], st));
-            if (k == CLS_WIDE) wide_aux = (int)sl.launches;
-        } else if (k == CLS_WIDE) wide_main = true;
+            if (k == CLS_WIDE) { launch_tb(k, st); wave_on_aux[a] = true; }     // the widest class's traceback follows its fill on its own stream
+            HIPCHK(c, hipEventRecord(sl.ev_join[a], st));
+        } else if (k == CLS_WIDE) wave_on_main[k] = true;
         sl.launches++;
     }
     HIPCHK(c, hipEventRecord(sl.t_fill1, s));
     for (int a = 0; a < NAUXS; a++)
-        if (used[a] && a != wide_aux) HIPCHK(c, hipStreamWaitEvent(s, sl.ev_join[a], 0));
-    if (wide_main) launch_tb(CLS_WIDE, s);
+        if (used[a] && !wave_on_aux[a]) HIPCHK(c, hipStreamWaitEvent(s, sl.ev_join[a], 0));
+    if (wave_on_main[CLS_WIDE]) launch_tb(CLS_WIDE, s);
     if (pl.cls_base[CLS_WIDE] > 0) launch_tb_lanes(s);
     HIPCHK(c, hipGetLastError());
-    if (wide_aux >= 0) HIPCHK(c, hipStreamWaitEvent(s, sl.ev_join[wide_aux], 0));
+    for (int a = 0; a < NAUXS; a++)
+        if (used[a] && wave_on_aux[a]) HIPCHK(c, hipStreamWaitEvent(s, sl.ev_join[a], 0));
     HIPCHK(c, hipEventRecord(sl.t_tb1, s));
     HIPCHK(c, hipEventRecord(sl.ev_done, s));
     return GBA_OK;
@@ -1779,7 +1806,7 @@ int fold_timing(gba_ctx *c, Slot &sl, TimeAcc &a)
     HIPCHK(c, hipEventElapsedTime(&t, c->ev[0], sl.t_tb1));
     a.f0 = x < a.f0 ? x : a.f0; a.f1 = e > a.f1 ? e : a.f1; a.tb1 = t > a.tb1 ? t : a.tb1;
     a.fill_sum += e - x;
-    a.wide += sl.pl.cls_count[CLS_WIDE];
+    a.wide += sl.pl.cls_count[CLS_WIDE] + sl.pl.cls_count[CLS_WNARROW];       // pairs filled one wave per pair
     a.launches += sl.launches; a.cells += sl.pl.total_cells; a.rows += sl.rows; a.rec += sl.pl.total_rec_dwords * 4;
     return GBA_OK;
 }
@@ -2059,6 +2086,8 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
             else (void)hipGetLastError();
         }
         if (const char *e = getenv("GBA_PART_PAIRS")) c->part_pairs = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char *e = getenv("GBA_WAVE_PAIRS")) c->wave_pairs = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char *e = getenv("GBA_WAVE_PAIRS_AFFINE")) c->wave_pairs_affine = (uint32_t)strtoul(e, nullptr, 10);
         for (int h = 0; h < NSLOT && !rc; h++) {
             Slot &sl = c->slot[h];
             if (h == 0) sl.s = c->stream;

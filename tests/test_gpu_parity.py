@@ -18,9 +18,20 @@ def api():
     return a
 
 
-@pytest.fixture(scope="module")
-def ctx(api):
+@pytest.fixture(scope="module", params=["lane-per-pair", "wave-per-pair"])
+def ctx(api, request):
+    """Every test that takes this context runs twice: with batches of any size on the lane-per-pair
+    kernels (rows too wide for them excepted), and with every batch on the wave-per-pair kernels
+    (the library itself sends batches too small to fill the GPU there)."""
+    old = {k: os.environ.get(k) for k in ("GBA_WAVE_PAIRS", "GBA_WAVE_PAIRS_AFFINE")}
+    v = "0" if request.param == "lane-per-pair" else "4000000000"
+    os.environ["GBA_WAVE_PAIRS"] = os.environ["GBA_WAVE_PAIRS_AFFINE"] = v
     c = api.Context(0, timing=True)
+    for k, o in old.items():
+        if o is None:
+            del os.environ[k]
+        else:
+            os.environ[k] = o
     yield c
     c.close()
 
