@@ -19,10 +19,16 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+ISA = os.path.join(_HERE, "csrc", "gba_gfx950.s")      # device assembly of the same source and flags (read by tests/test_isa.py)
+
+
 def build_libgba(force=False, extra=()):
     if force or _stale(LIBGBA, [SRC, HDR]):
         cmd = ["hipcc"] + HIPCC_FLAGS + list(extra) + ["-o", LIBGBA, SRC]
         subprocess.check_call(cmd)
+    if force or _stale(ISA, [SRC, HDR]):
+        flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+        subprocess.check_call(["hipcc"] + flags + list(extra) + ["-S", "--cuda-device-only", "-o", ISA, SRC])
     return LIBGBA
 
 
