@@ -59,7 +59,8 @@ constexpr uint32_t WN_SPAN = 124;
 static_assert(CLS_WNARROW == 3, "lane classes are 0..2");
 constexpr int LANE_CLS_LINEAR = 3;           // linear gaps: lane classes of 32, 64, 128 slots, anything wider is cheaper wave-per-pair
                                              // (a 96-slot class was measured: the batch gets slower, not faster)
-constexpr int LANE_CLS_AFFINE = 3;           // affine gaps: the same (two rings per wave)
+constexpr int LANE_CLS_AFFINE = 2;           // affine gaps: 32 and 64 slots; with two rings a wave of the 128-slot class takes 67 KB of LDS (two waves per CU), and
+                                             // the narrow wave-per-pair kernel is faster than that at any batch size (measured on 20 kb pairs, band 16)
 constexpr int PAD_SLOTS = 3;                 // spare slots behind a ring
 constexpr int SPAN_MARGIN = 4;               // a pair fits a class if its widest shift + width <= slots - SPAN_MARGIN (k_fill touches up to 7 slots past a row end)
 constexpr int CAP_LINEAR = 32, CAP_AFFINE = 40;   // cells per lane per step of k_fill (band 10 rows are 21+ cells, band 16 rows 33+)
