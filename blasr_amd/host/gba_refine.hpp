@@ -10,6 +10,7 @@
 #define GBA_REFINE_HPP
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -45,6 +46,8 @@ struct AlignmentCandidate {
     uint32_t nMatch = 0, nMismatch = 0, nIns = 0, nDel = 0;
     float pctSimilarity = 0;
     int status = 0;
+    float probScore = 0;           // the path under the probability scorer (StoreMapQVs, :135-151)
+    int mapQV = 0, numSignificantClusters = 1;
 };
 
 // RefineAlignment never assigns affineOpen / affineExtend of its two DistanceMatrixScoreFunction
@@ -320,6 +323,90 @@ inline int RefineAlignments(const std::string &read, std::vector<AlignmentCandid
         std::stable_sort(alignmentPtrs.begin(), alignmentPtrs.end(),
                          [](const AlignmentCandidate *a, const AlignmentCandidate *b) { return a->score < b->score; });
     return rc;
+}
+
+// ---- mapping qualities of one read's candidates: StoreMapQVs (:108-309) and its helpers.
+// What the device contributes is rawProbScore[i] = ComputeAlignmentScore of candidate i's path with
+// the probability scorer (SMRTLogProbMatrix, insertion / deletion / affine costs, :117-123): one of the
+// extra rescoring scorers of gba_scoring, returned in gba_pair_result.extra_score.  GetQInterval,
+// LogSumOfTwo and Phred are libcpp functions that are not in the reference tree (UNPINNED restatements).
+constexpr int kMaxPhredScore = 254, kMapQVEndAlignWiggle = 5;       // iblasr/BlasrHeaders.h:19-20
+
+inline void GetQInterval(const AlignmentCandidate &c, int &start, int &end)
+{
+    start = end = (int)(c.qAlignedSeqPos + c.qPos);
+    if (c.blocks.empty()) return;
+    end = start + (int)(c.blocks.back().qPos + c.blocks.back().length);
+    start += (int)c.blocks.front().qPos;
+}
+inline double LogSumOfTwo(double a, double b) { const double hi = a > b ? a : b, lo = a > b ? b : a; return hi + std::log10(1.0 + std::pow(10.0, lo - hi)); }
+inline int Phred(double p) { return (int)(-10.0 * std::log10(p)); }
+
+inline bool AlignmentsOverlap(const AlignmentCandidate &a, const AlignmentCandidate &b, float minPercentOverlap)      // :369-409
+{
+    int a0, a1, b0, b1, ovp = 0;
+    GetQInterval(a, a0, a1); GetQInterval(b, b0, b1);
+    if (a0 <= b0 && a1 >= b1) return true;
+    if (b0 <= a0 && b1 >= a1) return true;
+    if (a1 >= b0 && a1 <= b1) ovp = a1 - b0;
+    else if (a0 >= b0 && a0 <= b1) ovp = b1 - a0;
+    float pct = 0;
+    if (a1 - a0 > 0 && b1 - b0 > 0) pct = std::max(float(ovp) / float(a1 - a0), float(ovp) / float(b1 - b0));
+    return pct > minPercentOverlap;
+}
+
+inline void StoreMapQVs(std::vector<AlignmentCandidate *> &alignmentPtrs, const std::vector<int> &rawProbScore,
+                        float minFractionToBeConsideredOverlapping = 0.75f, int nCandidates = 10,
+                        bool scaleMapQVByNumSignificantClusters = false)
+{
+    const size_t n = alignmentPtrs.size();
+    for (size_t i = 0; i < n; i++) alignmentPtrs[i]->probScore = -(float)rawProbScore[i] / 10.0f;
+    std::vector<std::vector<int>> partitions;                        // PartitionOverlappingAlignments, :411-444
+    for (size_t i = 0; i < n; i++) {
+        bool found = false;
+        for (auto &part : partitions) {
+            for (int j : part) {
+                int i0, i1, j0, j1;
+                GetQInterval(*alignmentPtrs[i], i0, i1); GetQInterval(*alignmentPtrs[j], j0, j1);
+                if (AlignmentsOverlap(*alignmentPtrs[i], *alignmentPtrs[j], minFractionToBeConsideredOverlapping) || (i0 <= j0 && i1 > j1)) {
+                    part.push_back((int)i); found = true; break;
+                }
+            }
+            if (found) break;
+        }
+        if (!found) partitions.push_back(std::vector<int>{(int)i});
+    }
+    for (auto &part : partitions) {
+        int begin, end;
+        GetQInterval(*alignmentPtrs[part[0]], begin, end);
+        for (size_t k = 1; k < part.size(); k++) {
+            int s, e; GetQInterval(*alignmentPtrs[part[k]], s, e);
+            if (e - s > end - begin) { begin = s; end = e; }
+        }
+        for (int i : part) {                                         // :214-233, SumMismatches without quality values :362-365
+            int s, e; GetQInterval(*alignmentPtrs[i], s, e);
+            int mm = 0;
+            if (s - begin > kMapQVEndAlignWiggle || end - e > kMapQVEndAlignWiggle) mm = 15 * ((s - begin) + (end - e));
+            alignmentPtrs[i]->probScore += -(float)mm * 0.5f;
+        }
+        double denom = alignmentPtrs[part[0]]->probScore;
+        for (size_t k = 1; k < part.size(); k++) denom = LogSumOfTwo(denom, alignmentPtrs[part[k]]->probScore);
+        for (int i : part) {
+            AlignmentCandidate &c = *alignmentPtrs[i];
+            if (part.size() == 1) c.mapQV = kMaxPhredScore;
+            else if (c.probScore - denom < -20) c.mapQV = 0;
+            else {
+                const double expo = std::exp(std::log(10.0) * (c.probScore - denom)), diff = 1.0 - expo;
+                int q = expo == 0 ? 0 : diff == 0 ? kMaxPhredScore : Phred(diff);
+                c.mapQV = q > kMaxPhredScore ? kMaxPhredScore : q;
+            }
+            if (scaleMapQVByNumSignificantClusters) {                // ScaleMapQVByClusterSize, :97-106
+                if (c.numSignificantClusters > nCandidates)
+                    c.mapQV = Phred((1 - std::pow(10.0, c.mapQV / -10.0)) * ((float)nCandidates / c.numSignificantClusters));
+                else if (c.numSignificantClusters == 0) c.mapQV = 0;
+            }
+        }
+    }
 }
 
 }  // namespace gba

@@ -7,6 +7,7 @@
 //   reuse    hand every read to RefineBatch::Add through ONE std::string buffer that is overwritten
 //            for each candidate (what a parsing loop does)
 //   global   run the -global branch (RefineGlobal) on each (read, candidate) instead
+//   mapqv    no GPU: stdin is n, then "qStart qEnd rawProbScore" per candidate of ONE read; prints their mapQVs
 #include <cstdio>
 #include <iostream>
 
@@ -18,6 +19,22 @@ int main(int argc, char **argv)
     const bool cigar = mode == "cigar", reuse = mode == "reuse", global = mode == "global";
     size_t n;
     if (!(std::cin >> n)) return 2;
+    if (mode == "mapqv") {
+        std::vector<gba::AlignmentCandidate> cs(n);
+        std::vector<gba::AlignmentCandidate *> ptrs;
+        std::vector<int> raw(n);
+        for (size_t i = 0; i < n; i++) {
+            uint32_t q0, q1;
+            std::cin >> q0 >> q1 >> raw[i];
+            cs[i].qAlignedSeqPos = q0;
+            cs[i].blocks.push_back(gba::Block{0, 0, q1 - q0});
+            ptrs.push_back(&cs[i]);
+        }
+        gba::StoreMapQVs(ptrs, raw);
+        for (auto &c : cs) std::printf("%d ", c.mapQV);
+        std::printf("\n");
+        return 0;
+    }
     std::vector<std::string> reads(n);
     std::vector<gba::AlignmentCandidate> cands(n);
     for (size_t i = 0; i < n; i++) {

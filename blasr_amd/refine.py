@@ -62,6 +62,8 @@ class AlignmentCandidate:
     tAlignedSeqLength: int = 0
     qAlignedSeqLength: int = 0
     status: int = 0
+    probScore: float = 0.0
+    mapQV: int = 0
 
 
 # RefineAlignment never assigns affineOpen / affineExtend of its two DistanceMatrixScoreFunction
