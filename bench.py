@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host", action="store_true", help="skip the host-to-host measurement")
+    ap.add_argument("--cigar", type=int, default=None, help="also have the device write CIGAR operations (GBA_CIGAR_* flags); not part of the default line")
     ap.add_argument("--host-steps", type=int, default=6)
     ap.add_argument("--host-contexts", type=int, default=2)
     ap.add_argument("--host-child", action="store_true", help=argparse.SUPPRESS)
@@ -169,13 +170,16 @@ def main():
     out_blocks = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
     ctx = api.Context(local, timing=True)
     ctx.set_scoring(scoring)
+    cigar = None
+    if args.cigar is not None:
+        cigar = (torch.zeros(2 * cap, dtype=torch.int32, device=dev), torch.zeros(n + 1, dtype=torch.int64, device=dev), args.cigar)
 
     needed_dev = [0]
 
     def run_steps(count):
         fill = tb = 0.0
         for _ in range(count):
-            rc, needed = ctx.refine_device(dbatch, out_pairs, out_blocks)   # returns when the batch has completed
+            rc, needed = ctx.refine_device(dbatch, out_pairs, out_blocks, cigar=cigar)   # returns when the batch has completed
             if rc != 0:
                 raise RuntimeError("refine_device rc=%d needed=%d" % (rc, needed))
             needed_dev[0] = needed
@@ -261,6 +265,8 @@ def main():
         },
         "traceback_ms": round(tb_ms / args.steps, 3),
     }
+    if cigar is not None:
+        out["cigar"] = {"flags": args.cigar, "operations_per_step": ctx.cigar_needed}
 
     if rank == 0 and world == 1 and not args.no_host:
         # The same batch from host memory to host memory (gba_submit / gba_wait), measured by a child

@@ -19,6 +19,8 @@ NOALLOC_SCRATCH_BYTES = 64 << 20
 MODE_LINEAR, MODE_AFFINE, MODE_KBAND = 0, 1, 2
 TIE_DIAG_LEFT_UP, TIE_DIAG_UP_LEFT = 0, 1
 FLAG_TIMING = 1
+CIGAR_SEQ_MATCH, CIGAR_ADJACENT_INDELS = 1, 2
+CIGAR_OPS = "MIDNSHP=X"
 
 BLOCK_DT = np.dtype([("q_pos", "<u4"), ("t_pos", "<u4"), ("length", "<u4")])
 PAIR_RESULT_DT = np.dtype([
@@ -67,7 +69,9 @@ class Batch(C.Structure):
 
 class Results(C.Structure):
     _fields_ = [("pairs", C.c_void_p), ("blocks", C.c_void_p),
-                ("blocks_capacity", C.c_uint64), ("blocks_needed", C.c_uint64)]
+                ("blocks_capacity", C.c_uint64), ("blocks_needed", C.c_uint64),
+                ("cigar_ops", C.c_void_p), ("cigar_off", C.c_void_p),
+                ("cigar_capacity", C.c_uint64), ("cigar_needed", C.c_uint64), ("cigar_flags", C.c_uint32)]
 
 
 class Timing(C.Structure):

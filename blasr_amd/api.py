@@ -142,14 +142,19 @@ class Context:
                 out[k] = a
         return out
 
-    def submit_host(self, batch, pairs, blocks):
+    def submit_host(self, batch, pairs, blocks, cigar=None):
         """gba_submit: returns at once; `pairs` (ndarray[PAIR_RESULT_DT], one per pair) and `blocks`
         (ndarray[BLOCK_DT]) are filled while the batch runs and must not be read before
-        wait_host() has returned."""
+        wait_host() has returned.  cigar: optional (ops ndarray[uint32], off ndarray[uint64] of
+        n_pairs + 1, flags) to receive the CIGAR operations as well."""
         b, keep = make_batch_struct(batch)
         r = Results(_ptr(pairs), _ptr(blocks) if len(blocks) else None, len(blocks), 0)
+        if cigar is not None:
+            ops, off, flags = cigar
+            assert ops.dtype == np.uint32 and off.dtype == np.uint64 and len(off) >= int(batch["n_pairs"]) + 1 and len(ops) > 0
+            r.cigar_ops, r.cigar_off, r.cigar_capacity, r.cigar_flags = _ptr(ops), _ptr(off), len(ops), int(flags)
         self._check(self._L.gba_submit(self._h, C.byref(b), C.byref(r)))
-        self._flight = (b, keep, r, pairs, blocks)       # everything the running batch points into
+        self._flight = (b, keep, r, pairs, blocks, cigar)       # everything the running batch points into
 
     def wait_host(self):
         """gba_wait: blocks until the submitted batch is complete.  Returns (rc, blocks_needed)."""
@@ -157,6 +162,7 @@ class Context:
         r = self._flight[2]
         self._flight = None
         self.blocks_needed = int(r.blocks_needed)
+        self.cigar_needed = int(r.cigar_needed)
         return rc, self.blocks_needed
 
     def refine_host(self, batch, blocks_capacity=None):
@@ -171,14 +177,33 @@ class Context:
         rc, needed = self.wait_host()
         return pairs, blocks[:min(needed, int(blocks_capacity))], rc
 
+    def refine_host_cigar(self, batch, flags=_lib.CIGAR_SEQ_MATCH, cigar_capacity=None, blocks_capacity=None):
+        """refine_host that also returns the CIGAR operations: (pairs, blocks, ops, off, rc), the
+        operations of pair p being ops[off[p]:off[p + 1]] as length << 4 | BAM op code."""
+        n = int(batch["n_pairs"])
+        qsum = int(np.asarray(batch["q_len"]).astype(np.uint64).sum())
+        if blocks_capacity is None:
+            blocks_capacity = qsum + n
+        if cigar_capacity is None:      # every column its own operation
+            cigar_capacity = qsum + int(np.asarray(batch["t_len"]).astype(np.uint64).sum())
+        pairs = np.zeros(n, dtype=PAIR_RESULT_DT)
+        blocks = np.zeros(int(blocks_capacity), dtype=BLOCK_DT)
+        ops = np.zeros(max(int(cigar_capacity), 1), dtype=np.uint32)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        self.submit_host(batch, pairs, blocks, cigar=(ops, off, flags))
+        rc, needed = self.wait_host()
+        return pairs, blocks[:min(needed, int(blocks_capacity))], ops[:min(self.cigar_needed, len(ops))], off, rc
+
     # ---- device-resident tensors
-    def refine_device(self, dbatch, out_pairs, out_blocks, no_alloc=False):
+    def refine_device(self, dbatch, out_pairs, out_blocks, no_alloc=False, cigar=None):
         """dbatch: dict of torch CUDA tensors with the same keys as a host batch (uint8 arenas;
         offsets/lengths as int64/int32 tensors holding the uint64/uint32 bit patterns; blocks as
         an int32 tensor [n_blocks, 3]).  out_pairs: uint8 tensor of n*PAIR_RESULT_DT.itemsize
         bytes; out_blocks: int32 tensor [capacity, 3].  Returns (rc, blocks_needed).
         no_alloc: through gba_submit_device_noalloc (fixed scratch, no device allocation; a batch
-        that does not fit raises GbaError with code E_TOOBIG)."""
+        that does not fit raises GbaError with code E_TOOBIG).
+        cigar: optional (ops int32 tensor [capacity], off int64 tensor [n + 1], flags); the total number
+        of operations is left in self.cigar_needed."""
         n = int(dbatch["n_pairs"])
         ta = dbatch.get("t_arena")
         trc = dbatch.get("t_rc")
@@ -189,8 +214,13 @@ class Context:
                   trc.data_ptr() if trc is not None else None)
         assert out_pairs.numel() * out_pairs.element_size() >= n * PAIR_RESULT_DT.itemsize
         r = Results(out_pairs.data_ptr(), out_blocks.data_ptr(), out_blocks.shape[0], 0)
+        if cigar is not None:
+            ops, off, flags = cigar
+            assert ops.element_size() == 4 and off.element_size() == 8 and off.numel() >= n + 1 and ops.numel() > 0
+            r.cigar_ops, r.cigar_off, r.cigar_capacity, r.cigar_flags = ops.data_ptr(), off.data_ptr(), ops.numel(), int(flags)
         fn = self._L.gba_submit_device_noalloc if no_alloc else self._L.gba_submit_device
         rc = self._check(fn(self._h, C.byref(b), C.byref(r)), allow=(_lib.E_NOSPACE,))
+        self.cigar_needed = int(r.cigar_needed)
         return rc, int(r.blocks_needed)
 
 
@@ -224,10 +254,10 @@ class HostPipeline:
     def pinned_copy(self, batch):
         return self.ctxs[0].pinned_copy(batch)
 
-    def submit(self, batch, pairs, blocks):
+    def submit(self, batch, pairs, blocks, cigar=None):
         if self._sub - self._wait >= len(self.ctxs):
             raise GbaError(_lib.E_STATE)
-        self.ctxs[self._sub % len(self.ctxs)].submit_host(batch, pairs, blocks)
+        self.ctxs[self._sub % len(self.ctxs)].submit_host(batch, pairs, blocks, cigar=cigar)
         self._sub += 1
 
     def wait(self):

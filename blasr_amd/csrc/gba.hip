@@ -1516,6 +1516,152 @@ __global__ __launch_bounds__(256) void k_emit(Dev d, gba_pair_result *res, gba_b
     for (uint32_t x = threadIdx.x; x < nb; x += blockDim.x) dst[x] = src[x];
 }
 
+// ---------------------------------------------------------------- k_cigar
+// CIGAR operations of the refined pairs, in the BAM encoding.  One wave per pair, one lane per
+// "segment" = a gap-free block plus the gap that follows it.  With adjacent indels merged (the
+// default of the reference's writers) the part an insertion and a deletion have in common becomes
+// aligned columns, which extends the block's diagonal run; a segment is then: run aligned columns,
+// ni inserted query bases, nd deleted target bases.  A column starts a new operation when its
+// operation differs from the one of the column before, whichever segment that column belongs to;
+// the last operation of a segment follows from the segment alone, so a lane knows what precedes
+// it from its neighbour.  Two passes of the same walk: <false> counts the operations of each pair
+// (d.recdw, free after the tracebacks), and after a scan over the pairs <true> writes them:
+// first (column where the operation starts) << 4 | op at every start, then every entry's column is
+// replaced by the distance to the next start.
+// Bases are compared by their codes, like everywhere in this library (case-insensitive; two letters
+// outside ACGT count as the same).  The counting pass leaves the query's codes (code + 1, the form
+// of the target codes) at the start of the pair's traceback records, which nobody reads any more:
+// eight columns are then compared with two 8-byte loads and a handful of integer operations.
+typedef uint64_t u64u1 __attribute__((aligned(1)));
+
+// bit k: bytes k of a and b are equal, k < 8; all bytes are below 0x80
+__device__ __forceinline__ uint32_t equal_bytes(uint64_t a, uint64_t b)
+{
+    const uint64_t d = a ^ b;
+    // 0x80 - d keeps bit 7 exactly where d is zero, and no byte borrows from the next
+    const uint64_t e = (0x8080808080808080ull - d) & 0x8080808080808080ull;
+    const uint32_t lo = (uint32_t)e >> 7, hi = (uint32_t)(e >> 32) >> 7;      // bits 0, 8, 16, 24
+    // the four bits of a half gathered into bits 24..27 by one multiplication (no two products share a bit)
+    constexpr uint32_t G = 1u << 24 | 1u << 17 | 1u << 10 | 1u << 3;
+    return (lo * G) >> 24 | ((hi * G) >> 24) << 4;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_cigar(Dev d, uint32_t flags, const uint64_t *off, uint32_t *ops, uint64_t capacity)
+{
+    const uint32_t p = blockIdx.x, lane = threadIdx.x;
+    const uint32_t nb = d.status[p] == GBA_PAIR_OK ? d.span[p] : 0u;
+    if (nb == 0) {
+        if (!WRITE && lane == 0) d.recdw[p] = 0;
+        return;
+    }
+    const uint32_t nops = WRITE ? d.recdw[p] : 0u;
+    uint32_t *out = nullptr;
+    if (WRITE) {
+        const uint64_t o = off[p];
+        if (o + nops > capacity) return;             // the caller's arena is too small: the entry point reports it
+        out = ops + o;
+    }
+    const uint32_t Q = d.Q[p];
+    const gba_block *bl = d.blk_scratch + d.row_off[p] + (Q + 1 - nb);
+    const uint8_t *tc = d.tcodes + tc_offset(d, p) + 1;      // tc[x]: code + 1 of the target base x columns after t_pos
+    uint8_t *qc = (uint8_t *)(d.rec + d.rec_off[p]);         // qc[x]: the same for the query base x rows after q_pos
+    const bool seqm = (flags & GBA_CIGAR_SEQ_MATCH) != 0, adj = (flags & GBA_CIGAR_ADJACENT_INDELS) != 0;
+    if (!WRITE && seqm) {
+        // a row's record is at least two dwords, so Q + 8 bytes fit the pair's records
+        const uint8_t *q = d.q_arena + d.q_off[p] + d.qS[p];
+        for (uint32_t x0 = 4 * lane; x0 < Q + 8; x0 += 256) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) w |= (x0 + x < Q ? base_code(q[x0 + x]) + 1u : 6u) << (8 * x);   // past the end: equal to no target code
+            *(uint32_t *)(qc + x0) = w;
+        }
+        __syncthreads();
+    }
+    uint32_t carry_op = 0xffu, carry_cnt = 0, carry_col = 0;
+    for (uint32_t s0 = 0; s0 < nb; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        uint32_t bq = 0, bt = 0, run = 0, ni = 0, nd = 0, last = 0xffu;
+        if (s < nb) {
+            const gba_block b = bl[s];
+            bq = b.q_pos; bt = b.t_pos; run = b.length;
+            if (s + 1 < nb) {
+                const gba_block nx = bl[s + 1];
+                ni = nx.q_pos - (bq + run); nd = nx.t_pos - (bt + run);
+                if (!adj && ni && nd) { const uint32_t cm = ni < nd ? ni : nd; run += cm; ni -= cm; nd -= cm; }
+            }
+            last = nd ? (uint32_t)GBA_CIGAR_D : ni ? (uint32_t)GBA_CIGAR_I : !seqm ? (uint32_t)GBA_CIGAR_M
+                 : qc[bq + run - 1] == tc[bt + run - 1] ? (uint32_t)GBA_CIGAR_EQ : (uint32_t)GBA_CIGAR_X;
+        }
+        const uint32_t before = wave_prev(last, carry_op);
+        // walk(starts, emit): starts(n) for n operations that start in aligned columns (counting only),
+        // or emit(column within the segment, op) for every operation that starts in the segment
+        auto walk = [&](auto &&emit, bool counting, uint32_t &count) {
+            uint32_t prev = before;
+            if (!seqm) {
+                if (run && prev != GBA_CIGAR_M) { if (counting) count++; else emit(0u, (uint32_t)GBA_CIGAR_M); }
+                if (run) prev = GBA_CIGAR_M;
+            } else {
+                for (uint32_t k = 0; k < run; k += 8) {
+                    const uint32_t n = run - k < 8u ? run - k : 8u;
+                    const uint32_t m = equal_bytes(*(const u64u1 *)(qc + bq + k), *(const u64u1 *)(tc + bt + k)) & ((1u << n) - 1u);
+                    // a column starts an operation when it differs from the column before it
+                    uint32_t st = (m ^ (m << 1 | (prev == GBA_CIGAR_EQ ? 1u : 0u))) & ((1u << n) - 1u);
+                    if (prev != GBA_CIGAR_EQ && prev != GBA_CIGAR_X) st |= 1u;
+                    if (counting) count += (uint32_t)__builtin_popcount(st);
+                    else while (st) {
+                        const uint32_t x = (uint32_t)__builtin_ctz(st);
+                        emit(k + x, (m >> x & 1u) ? (uint32_t)GBA_CIGAR_EQ : (uint32_t)GBA_CIGAR_X);
+                        st &= st - 1u;
+                    }
+                    prev = (m >> (n - 1u) & 1u) ? (uint32_t)GBA_CIGAR_EQ : (uint32_t)GBA_CIGAR_X;
+                }
+            }
+            if (ni) { if (prev != GBA_CIGAR_I) { if (counting) count++; else emit(run, (uint32_t)GBA_CIGAR_I); } prev = GBA_CIGAR_I; }
+            if (nd && prev != GBA_CIGAR_D) { if (counting) count++; else emit(run + ni, (uint32_t)GBA_CIGAR_D); }
+        };
+        uint32_t cnt = 0, unused = 0;
+        walk([](uint32_t, uint32_t) {}, true, cnt);
+        const uint32_t cnt_incl = wave_scan_sum(cnt);
+        if (WRITE) {
+            const uint32_t cols = run + ni + nd;
+            const uint32_t col_incl = wave_scan_sum(cols);
+            uint32_t at = carry_cnt + cnt_incl - cnt;
+            const uint32_t col0 = carry_col + col_incl - cols;
+            walk([&](uint32_t k, uint32_t op) { out[at++] = (col0 + k) << 4 | op; }, false, unused);
+            carry_col += (uint32_t)__builtin_amdgcn_readlane((int32_t)col_incl, 63);
+        }
+        carry_cnt += (uint32_t)__builtin_amdgcn_readlane((int32_t)cnt_incl, 63);
+        carry_op = (uint32_t)__builtin_amdgcn_readlane((int32_t)last, 63);
+    }
+    if (!WRITE) {
+        if (lane == 0) d.recdw[p] = carry_cnt;
+        return;
+    }
+    __syncthreads();                                 // the starts written by other lanes are visible
+    for (uint32_t i0 = 0; i0 < nops; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        uint32_t w = 0, next = carry_col;            // the last operation ends with the alignment
+        if (i < nops) { w = out[i]; if (i + 1 < nops) next = out[i + 1] >> 4; }
+        __syncthreads();                             // every lane has read its neighbour's entry before anyone rewrites one
+        if (i < nops) out[i] = (next - (w >> 4)) << 4 | (w & 15u);
+    }
+}
+
+// Operation counts (d.recdw) -> offsets into the caller's operation arena, for the pairs of one
+// part (single block).  *carry holds the operations of the parts scanned before and receives the
+// sum; off[d.n] is the offset one past the part (the next part's first pair rewrites the same value).
+__global__ __launch_bounds__(SCAN_T) void k_scan_ops(Dev d, uint64_t *carry, uint64_t *off)
+{
+    __shared__ uint64_t sm[17];
+    const uint64_t c0 = *carry;
+    __syncthreads();
+    const uint64_t tot = scan_array(d.recdw, off, d.n, sm);
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < d.n; p += blockDim.x) off[p] += c0;
+    if (threadIdx.x == 0) { off[d.n] = c0 + tot; *carry = c0 + tot; }
+}
+
 // ================================================================ host side
 struct Buf {
     void *ptr = nullptr;
@@ -1538,8 +1684,9 @@ constexpr int NAUXS = 2;      // auxiliary streams per slot (wider classes run b
 struct Slot {
     Buf b_plan, b_guide, b_tc, b_rec, b_blk;     // device scratch (grow-only)
     Buf b_out;                                   // host-buffer batches: the packed blocks of the part in this slot, on their way to the host
+    Buf b_cig;                                   // the same for its CIGAR operations
     Plan *h_plan = nullptr;                      // pinned
-    uint64_t *h_cnt = nullptr;                   // pinned: blocks of the batch up to and including the part in this slot
+    uint64_t *h_cnt = nullptr;                   // pinned: blocks [0] and CIGAR operations [1] of the batch up to and including the part in this slot
     hipStream_t s = nullptr, aux[NAUXS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[NAUXS] = {}, ev_done = nullptr, ev_scan = nullptr;
     hipEvent_t ev_cnt = nullptr, ev_emit = nullptr, ev_d2h = nullptr;   // host-buffer batches: count read back; blocks packed; blocks copied out
@@ -1576,7 +1723,7 @@ struct gba_ctx {
     Buf b_pair32[14], b_pair64[5], b_needed;
     Slot slot[NSLOT];
     // host-buffer batches: device copies of the caller's batch, the copy streams, the worker thread
-    Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res;
+    Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res, s_cigoff;
     hipStream_t s_in = nullptr, s_out = nullptr;     // host-to-device and device-to-host copies, beside the kernels
     std::vector<hipEvent_t> ev_in;                   // per part: its inputs have arrived
     std::vector<void *> host_allocs;                 // gba_host_alloc
@@ -1819,6 +1966,8 @@ struct HostIO {
     gba_pair_result *d_res;       // device copy of the pair results
     bool all_ahead = false;       // every part's inputs are queued at once (page-locked arenas, a hardware queue to spare)
     uint64_t need_before = 0;     // blocks of the parts emitted so far
+    uint64_t ops_before = 0;      // CIGAR operations of the parts emitted so far
+    uint64_t *d_cigoff = nullptr; // device copy of the operation offsets (n_pairs + 1), null: no CIGARs wanted
     // byte / element ranges of the three arenas that are on the device already
     uint64_t have[3][2] = {{0, 0}, {0, 0}, {0, 0}};
 };
@@ -1882,18 +2031,26 @@ int stage_part(gba_ctx *c, HostIO &io, uint32_t first, uint32_t cnt, hipEvent_t 
 int finish_part(gba_ctx *c, HostIO &io, Slot &sl)
 {
     HIPCHK(c, hipEventSynchronize(sl.ev_cnt));
-    const uint64_t after = *sl.h_cnt, before = io.need_before, cnt = after - before;
+    const uint64_t after = sl.h_cnt[0], before = io.need_before, cnt = after - before;
     const uint64_t cap = io.hout->blocks_capacity;
     const uint64_t fit = before >= cap ? 0 : (after <= cap ? cnt : cap - before);     // blocks of this part the caller's arena takes
+    const bool cig = io.d_cigoff != nullptr;
+    const uint64_t ops_after = cig ? sl.h_cnt[1] : 0, ops_before = io.ops_before, ops_cnt = ops_after - ops_before;
+    const uint64_t ops_cap = io.hout->cigar_capacity;
+    const uint64_t ops_fit = ops_before >= ops_cap ? 0 : (ops_after <= ops_cap ? ops_cnt : ops_cap - ops_before);
     if (sl.d2h_pending) {
-        // the previous part of this slot may still be copying out of b_out
-        if ((size_t)cnt * sizeof(gba_block) > sl.b_out.cap) HIPCHK(c, hipEventSynchronize(sl.ev_d2h));
+        // the previous part of this slot may still be copying out of b_out / b_cig
+        if ((size_t)cnt * sizeof(gba_block) > sl.b_out.cap || (size_t)ops_cnt * 4 > sl.b_cig.cap) HIPCHK(c, hipEventSynchronize(sl.ev_d2h));
         else HIPCHK(c, hipStreamWaitEvent(sl.s, sl.ev_d2h, 0));
     }
     { int rc = ensure(c, sl.b_out, (size_t)cnt * sizeof(gba_block) + 16); if (rc) return rc; }
+    if (cig) { int rc = ensure(c, sl.b_cig, (size_t)ops_cnt * 4 + 16); if (rc) return rc; }
     // offsets are those of the whole batch (that is what the caller's arena is indexed by), so the
     // part's buffer is addressed as if it began `before` blocks earlier
     hipLaunchKernelGGL(k_emit, dim3(sl.dev.n), dim3(256), 0, sl.s, sl.dev, io.d_res + sl.first, (gba_block *)sl.b_out.ptr - before, cap);
+    if (cig)
+        hipLaunchKernelGGL(k_cigar<true>, dim3(sl.dev.n), dim3(64), 0, sl.s, sl.dev, io.hout->cigar_flags, io.d_cigoff + sl.first,
+                           (uint32_t *)sl.b_cig.ptr - ops_before, ops_cap);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(sl.ev_emit, sl.s));
     HIPCHK(c, hipEventRecord(sl.ev_done, sl.s));
@@ -1902,9 +2059,16 @@ int finish_part(gba_ctx *c, HostIO &io, Slot &sl)
                              hipMemcpyDeviceToHost, c->s_out));
     if (fit && io.hout->blocks)
         HIPCHK(c, hipMemcpyAsync(io.hout->blocks + before, sl.b_out.ptr, (size_t)fit * sizeof(gba_block), hipMemcpyDeviceToHost, c->s_out));
+    if (cig) {
+        // the entry one past the part is the next part's first (the same value) or the end of the batch
+        HIPCHK(c, hipMemcpyAsync(io.hout->cigar_off + sl.first, io.d_cigoff + sl.first, ((size_t)sl.dev.n + 1) * 8, hipMemcpyDeviceToHost, c->s_out));
+        if (ops_fit)
+            HIPCHK(c, hipMemcpyAsync(io.hout->cigar_ops + ops_before, sl.b_cig.ptr, (size_t)ops_fit * 4, hipMemcpyDeviceToHost, c->s_out));
+    }
     HIPCHK(c, hipEventRecord(sl.ev_d2h, c->s_out));
     sl.d2h_pending = true;
     io.need_before = after;
+    io.ops_before = ops_after;
     return GBA_OK;
 }
 
@@ -1921,12 +2085,18 @@ int finish_part(gba_ctx *c, HostIO &io, Slot &sl)
 int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nullptr)
 {
     const uint32_t n = b->n_pairs;
-    out->blocks_needed = 0;
-    if (n == 0) return GBA_OK;
+    const bool cig = io ? io->d_cigoff != nullptr : out->cigar_ops != nullptr;
+    uint64_t *cig_off = io ? io->d_cigoff : out->cigar_off;
+    out->blocks_needed = 0; out->cigar_needed = 0;
     HIPCHK(c, hipSetDevice(c->device));
+    if (n == 0) {
+        if (cig && io) io->hout->cigar_off[0] = 0;
+        else if (cig) { HIPCHK(c, hipMemsetAsync(cig_off, 0, 8, c->slot[0].s)); HIPCHK(c, hipStreamSynchronize(c->slot[0].s)); }
+        return GBA_OK;
+    }
     for (int i = 0; i < 14; i++) { int rc = ensure(c, c->b_pair32[i], (size_t)n * 4); if (rc) return rc; }
     for (int i = 0; i < 5; i++) { int rc = ensure(c, c->b_pair64[i], (size_t)n * 8); if (rc) return rc; }
-    { int rc = ensure(c, c->b_needed, 8); if (rc) return rc; }
+    { int rc = ensure(c, c->b_needed, 16); if (rc) return rc; }
     for (auto &sl : c->slot) { int rc = ensure(c, sl.b_plan, sizeof(Plan)); if (rc) return rc; }
     Dev g;
     memset(&g, 0, sizeof(g));
@@ -1980,7 +2150,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
         }
     }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    HIPCHK(c, hipMemsetAsync(needed, 0, 8, s));
+    HIPCHK(c, hipMemsetAsync(needed, 0, 16, s));
     if (parts > 1) {                                   // the second slot's stream starts after the batch's inputs are ready
         HIPCHK(c, hipEventRecord(c->slot[0].ev_fork, s));
         HIPCHK(c, hipStreamWaitEvent(c->slot[1].s, c->slot[0].ev_fork, 0));
@@ -2000,29 +2170,35 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
             const uint32_t nf = (h + 1) * per;
             rc = stage_part(c, *io, nf, n - nf < per ? n - nf : per, c->ev_in[h + 1]); if (rc) return rc;
         }
-        // block offsets continue where the part before stopped
+        if (cig) hipLaunchKernelGGL(k_cigar<false>, dim3(d.n), dim3(64), 0, sl.s, d, out->cigar_flags, (const uint64_t *)nullptr, (uint32_t *)nullptr, 0ull);
+        // block (and operation) offsets continue where the part before stopped
         if (h > 0) HIPCHK(c, hipStreamWaitEvent(sl.s, c->slot[(h - 1) % NSLOT].ev_scan, 0));
         hipLaunchKernelGGL(k_scan1, dim3(1), dim3(SCAN_T), 0, sl.s, d, needed);
+        if (cig) hipLaunchKernelGGL(k_scan_ops, dim3(1), dim3(SCAN_T), 0, sl.s, d, needed + 1, cig_off + first);
         HIPCHK(c, hipEventRecord(sl.ev_scan, sl.s));
         if (io) {
             sl.dev = d; sl.first = first;
-            HIPCHK(c, hipMemcpyAsync(sl.h_cnt, needed, 8, hipMemcpyDeviceToHost, sl.s));
+            HIPCHK(c, hipMemcpyAsync(sl.h_cnt, needed, 16, hipMemcpyDeviceToHost, sl.s));
             HIPCHK(c, hipEventRecord(sl.ev_cnt, sl.s));
             HIPCHK(c, hipEventRecord(sl.ev_done, sl.s));
             if (h > 0) { rc = finish_part(c, *io, c->slot[(h - 1) % NSLOT]); if (rc) return rc; }
             continue;
         }
         hipLaunchKernelGGL(k_emit, dim3(d.n), dim3(256), 0, sl.s, d, res + first, out->blocks, out->blocks_capacity);
+        if (cig)
+            hipLaunchKernelGGL(k_cigar<true>, dim3(d.n), dim3(64), 0, sl.s, d, out->cigar_flags, (const uint64_t *)(cig_off + first),
+                               out->cigar_ops, out->cigar_capacity);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(sl.ev_done, sl.s));
     }
     if (io) { int rc = finish_part(c, *io, c->slot[(parts - 1) % NSLOT]); if (rc) return rc; }
     if (parts > 1) HIPCHK(c, hipStreamWaitEvent(s, c->slot[1].ev_done, 0));
-    HIPCHK(c, hipMemcpyAsync(c->h_needed, needed, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_needed, needed, 16, hipMemcpyDeviceToHost, s));
     if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (io) HIPCHK(c, hipStreamSynchronize(c->s_out));
-    out->blocks_needed = *c->h_needed;
+    out->blocks_needed = c->h_needed[0];
+    out->cigar_needed = cig ? c->h_needed[1] : 0;
     if (timing) {
         // fill: the bulk fill launches of the parts, one after the other (what else runs on the GPU
         // during a launch makes it longer); traceback: from the last fill's end to the last traceback's
@@ -2033,7 +2209,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
         t.fill_ms = acc.fill_sum; t.traceback_ms = acc.tb1 > acc.f1 ? acc.tb1 - acc.f1 : 0;
         HIPCHK(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[1]));
     }
-    return out->blocks_needed > out->blocks_capacity ? GBA_E_NOSPACE : GBA_OK;
+    return out->blocks_needed > out->blocks_capacity || out->cigar_needed > out->cigar_capacity ? GBA_E_NOSPACE : GBA_OK;
 }
 
 }  // namespace
@@ -2078,7 +2254,7 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
         if (hipSetDevice(c->device) != hipSuccess) { rc = GBA_E_HIP; break; }
         if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
         else { if (hipStreamCreate(&c->stream) != hipSuccess) { rc = GBA_E_HIP; break; } c->own_stream = true; }
-        if (hipHostMalloc((void **)&c->h_needed, 8) != hipSuccess) { rc = GBA_E_NOMEM; break; }
+        if (hipHostMalloc((void **)&c->h_needed, 16) != hipSuccess) { rc = GBA_E_NOMEM; break; }
         for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rc = GBA_E_HIP; break; }
         if (rc) break;
         {   // this device's copy of the no-allocation scratch (the ctx stays usable without it)
@@ -2094,7 +2270,7 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
             if (h == 0) sl.s = c->stream;
             else if (hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking) != hipSuccess) { rc = GBA_E_HIP; break; }
             if (hipHostMalloc((void **)&sl.h_plan, sizeof(Plan)) != hipSuccess) { rc = GBA_E_NOMEM; break; }
-            if (hipHostMalloc((void **)&sl.h_cnt, 8) != hipSuccess) { rc = GBA_E_NOMEM; break; }
+            if (hipHostMalloc((void **)&sl.h_cnt, 16) != hipSuccess) { rc = GBA_E_NOMEM; break; }
             hipEvent_t *plain[] = {&sl.ev_fork, &sl.ev_done, &sl.ev_scan, &sl.ev_join[0], &sl.ev_join[1], &sl.ev_cnt, &sl.ev_emit, &sl.ev_d2h};
             for (hipEvent_t *e : plain) if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) rc = GBA_E_HIP;
             hipEvent_t *timed[] = {&sl.t_fill0, &sl.t_fill1, &sl.t_tb1};
@@ -2135,7 +2311,7 @@ void gba_destroy(gba_ctx *c)
     for (auto &b : c->b_pair64) release(b);
     Buf *bs[] = {&c->b_ref, &c->s_trc, &c->b_needed,
                  &c->s_q, &c->s_t, &c->s_blk, &c->s_qoff, &c->s_toff, &c->s_boff, &c->s_qlen, &c->s_tlen,
-                 &c->s_nblk, &c->s_res};
+                 &c->s_nblk, &c->s_res, &c->s_cigoff};
     for (Buf *b : bs) release(*b);
     if (c->h_needed) (void)hipHostFree(c->h_needed);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -2143,7 +2319,7 @@ void gba_destroy(gba_ctx *c)
         Slot &sl = c->slot[h];
         for (int a = 0; a < NAUXS; a++) if (sl.aux[a]) { (void)hipStreamSynchronize(sl.aux[a]); (void)hipStreamDestroy(sl.aux[a]); }
         if (h > 0 && sl.s) { (void)hipStreamSynchronize(sl.s); (void)hipStreamDestroy(sl.s); }
-        Buf *sb[] = {&sl.b_plan, &sl.b_guide, &sl.b_tc, &sl.b_rec, &sl.b_blk, &sl.b_out};
+        Buf *sb[] = {&sl.b_plan, &sl.b_guide, &sl.b_tc, &sl.b_rec, &sl.b_blk, &sl.b_out, &sl.b_cig};
         for (Buf *b : sb) release(*b);
         if (sl.h_plan) (void)hipHostFree(sl.h_plan);
         if (sl.h_cnt) (void)hipHostFree(sl.h_cnt);
@@ -2238,6 +2414,7 @@ int gba_submit_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     if (!c || !b || !out) return GBA_E_INVALID;
     if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
     if (b->n_pairs && (!out->pairs || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
+    if (out->cigar_ops && !out->cigar_off) return GBA_E_INVALID;
     if (!batch_complete(b)) return GBA_E_INVALID;
     if (!b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
     return run_device(c, b, out);
@@ -2248,6 +2425,7 @@ int gba_submit_device_noalloc(gba_ctx *c, const gba_batch *b, gba_results *out)
     if (!c || !b || !out) return GBA_E_INVALID;
     if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
     if (b->n_pairs && (!out->pairs || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
+    if (out->cigar_ops && !out->cigar_off) return GBA_E_INVALID;
     if (!batch_complete(b)) return GBA_E_INVALID;
     if (!b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
     if (!c->fixed_base) return GBA_E_HIP;             // hipGetSymbolAddress failed in gba_create
@@ -2273,8 +2451,9 @@ int gba_submit_device_noalloc(gba_ctx *c, const gba_batch *b, gba_results *out)
 static int run_host_batch(gba_ctx *c, const gba_batch *b, gba_results *out)
 {
     const uint32_t n = b->n_pairs;
-    out->blocks_needed = 0;
-    if (n == 0) return GBA_OK;
+    const bool cig = out->cigar_ops != nullptr;
+    out->blocks_needed = 0; out->cigar_needed = 0;
+    if (n == 0) { if (cig) out->cigar_off[0] = 0; return GBA_OK; }
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     struct { Buf *buf; size_t bytes; } need[] = {
@@ -2282,7 +2461,8 @@ static int run_host_batch(gba_ctx *c, const gba_batch *b, gba_results *out)
         {&c->s_blk, (size_t)b->n_blocks_total * sizeof(gba_block)},
         {&c->s_qoff, (size_t)n * 8}, {&c->s_toff, (size_t)n * 8}, {&c->s_boff, (size_t)n * 8},
         {&c->s_qlen, (size_t)n * 4}, {&c->s_tlen, (size_t)n * 4}, {&c->s_nblk, (size_t)n * 4},
-        {&c->s_trc, b->t_rc ? (size_t)n : 0}, {&c->s_res, (size_t)n * sizeof(gba_pair_result)}};
+        {&c->s_trc, b->t_rc ? (size_t)n : 0}, {&c->s_res, (size_t)n * sizeof(gba_pair_result)},
+        {&c->s_cigoff, cig ? ((size_t)n + 1) * 8 : 0}};
     for (auto &x : need) if ((rc = ensure(c, *x.buf, x.bytes + 16))) return rc;
     gba_batch db = *b;
     db.q_arena = (const uint8_t *)c->s_q.ptr; db.t_arena = b->t_arena ? (const uint8_t *)c->s_t.ptr : nullptr;
@@ -2293,10 +2473,13 @@ static int run_host_batch(gba_ctx *c, const gba_batch *b, gba_results *out)
     db.q_len = (const uint32_t *)c->s_qlen.ptr; db.t_len = (const uint32_t *)c->s_tlen.ptr;
     db.n_blk = (const uint32_t *)c->s_nblk.ptr;
     gba_results dr;
-    dr.pairs = (gba_pair_result *)c->s_res.ptr; dr.blocks = nullptr;
-    dr.blocks_capacity = out->blocks_capacity; dr.blocks_needed = 0;
+    memset(&dr, 0, sizeof(dr));
+    dr.pairs = (gba_pair_result *)c->s_res.ptr;
+    dr.blocks_capacity = out->blocks_capacity;
+    dr.cigar_capacity = out->cigar_capacity; dr.cigar_flags = out->cigar_flags;
     HostIO io;
     io.hb = b; io.hout = out; io.d_res = dr.pairs;
+    if (cig) io.d_cigoff = (uint64_t *)c->s_cigoff.ptr;
     // Page-locked arenas (gba_host_alloc, or pinned / registered by the caller) are copied by the copy
     // engines without the calling thread; when the runtime also has a hardware queue to spare for the
     // copy stream (GPU_MAX_HW_QUEUES of 8 or more; with the default 4 it shares one with a kernel stream,
@@ -2310,7 +2493,7 @@ static int run_host_batch(gba_ctx *c, const gba_batch *b, gba_results *out)
     const char *hq = getenv("GPU_MAX_HW_QUEUES");
     io.all_ahead = hq && atoi(hq) >= 8 && pinned(b->q_arena) && pinned(b->blocks) && (!b->t_arena || pinned(b->t_arena));
     rc = run_device(c, &db, &dr, &io);
-    out->blocks_needed = dr.blocks_needed;
+    out->blocks_needed = dr.blocks_needed; out->cigar_needed = dr.cigar_needed;
     return rc;
 }
 
@@ -2342,6 +2525,7 @@ int gba_submit(gba_ctx *c, const gba_batch *b, gba_results *out)
     if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
     if (!batch_complete(b)) return GBA_E_INVALID;
     if (b->n_pairs && (!out->pairs || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
+    if (out->cigar_ops && !out->cigar_off) return GBA_E_INVALID;
     if (b->n_pairs && !b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
     std::unique_lock<std::mutex> lk(c->mu);
     if (!c->worker.joinable()) {

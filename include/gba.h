@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GBA_VERSION 300   /* major*10000 + minor*100 + patch */
+#define GBA_VERSION 310   /* major*10000 + minor*100 + patch */
 
 /* return codes of the entry points */
 enum {
@@ -145,11 +145,29 @@ typedef struct {
     int32_t extra_score[GBA_MAX_EXTRA];   /* the path under gba_scoring.extra[] */
 } gba_pair_result;
 
+/* CIGAR operations in the BAM encoding (length << 4 | op), the text-ready form of a refined
+ * alignment that the reference's SAM / BAM writers derive from blocks and sequences
+ * (SAMOutput / BAMOutput::PrintAlignment with params.cigarUseSeqMatch and
+ * params.allowAdjacentIndels, iblasr/BlasrUtilsImpl.hpp:969-974).  Soft / hard clips are the
+ * writer's business (they depend on --clipping and on the full read) and are not emitted. */
+enum { GBA_CIGAR_M = 0, GBA_CIGAR_I = 1, GBA_CIGAR_D = 2, GBA_CIGAR_EQ = 7, GBA_CIGAR_X = 8 };
+#define GBA_CIGAR_SEQ_MATCH 1u              /* gap-free columns as runs of = and X (cigarUseSeqMatch); otherwise one M per run */
+#define GBA_CIGAR_ADJACENT_INDELS 2u        /* keep an insertion next to a deletion as they are (-allowAdjacentIndels); otherwise the
+                                               part the two have in common becomes aligned columns, RegisterBlasrOptions.h:254-259 */
+
 typedef struct {
     gba_pair_result *pairs;     /* n_pairs entries */
     gba_block *blocks;          /* arena for all pairs' blocks, relative to (q_pos, t_pos) */
     uint64_t blocks_capacity;   /* in blocks */
     uint64_t blocks_needed;     /* out: total blocks of the batch */
+    /* optional (cigar_ops == NULL: not wanted): the CIGAR of every aligned pair, packed in input order */
+    uint32_t *cigar_ops;        /* arena for all pairs' operations */
+    uint64_t *cigar_off;        /* n_pairs + 1 entries: the operations of pair p are cigar_ops[cigar_off[p] .. cigar_off[p + 1]);
+                                   pairs that were not aligned have none */
+    uint64_t cigar_capacity;    /* in operations */
+    uint64_t cigar_needed;      /* out: total operations of the batch; beyond cigar_capacity nothing is written and the
+                                   entry point returns GBA_E_NOSPACE */
+    uint32_t cigar_flags;       /* GBA_CIGAR_* */
 } gba_results;
 
 /* live measurements of the last waited batch (GBA_FLAG_TIMING) */

@@ -27,7 +27,7 @@ def test_exports_match_header():
 def test_version_and_strerror():
     from blasr_amd import _lib
     L = _lib.lib()
-    assert L.gba_version() == 300
+    assert L.gba_version() == 310
     assert L.gba_strerror(0) == b"ok"
     assert b"arena" in L.gba_strerror(_lib.E_NOSPACE)
     assert b"unknown" in L.gba_strerror(12345)
@@ -40,7 +40,7 @@ def test_struct_layouts():
     assert C.sizeof(_lib.Rescorer) == (25 + 5) * 4
     assert C.sizeof(_lib.Scoring) == (25 + 14 + 1 + 2 * 30) * 4
     assert C.sizeof(_lib.Batch) == 8 + 9 * 8 + 3 * 8 + 8
-    assert C.sizeof(_lib.Results) == 32
+    assert C.sizeof(_lib.Results) == 72
 
 
 def test_argument_errors_without_gpu():
