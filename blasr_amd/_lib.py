@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GBA_LIB", os.path.join(_HERE, "libgba.so"))   # GBA_L
 OK, E_INVALID, E_NOMEM, E_HIP, E_NOSPACE, E_UNSUPPORTED, E_STATE, E_TOOBIG = 0, -1, -2, -3, -4, -5, -6, -7
 NOALLOC_SCRATCH_BYTES = 64 << 20
 (PAIR_OK, PAIR_EMPTY_GUIDE, PAIR_BAD_GUIDE, PAIR_UNREACHABLE, PAIR_NOSPACE,
- PAIR_END_OUT_OF_BAND, PAIR_TOO_WIDE, PAIR_TOO_LONG) = range(8)
+ PAIR_END_OUT_OF_BAND, PAIR_TOO_WIDE, PAIR_TOO_LONG, PAIR_TOO_MANY) = range(9)
 MODE_LINEAR, MODE_AFFINE, MODE_KBAND = 0, 1, 2
 TIE_DIAG_LEFT_UP, TIE_DIAG_UP_LEFT = 0, 1
 FLAG_TIMING = 1
@@ -80,8 +80,18 @@ class Timing(C.Structure):
                 ("record_bytes", C.c_uint64), ("wide_pairs", C.c_uint32)]
 
 
+class SdpParams(C.Structure):
+    _fields_ = [("tuple_size", C.c_int32), ("ins", C.c_int32), ("dele", C.c_int32), ("match", C.c_int32),
+                ("max_fragments", C.c_uint32)]
+
+
+class Guides(C.Structure):
+    _fields_ = [("status", C.c_void_p), ("chain_score", C.c_void_p), ("n_blk", C.c_void_p), ("blk_off", C.c_void_p),
+                ("blocks", C.c_void_p), ("blocks_capacity", C.c_uint64), ("blocks_needed", C.c_uint64)]
+
+
 EXPORTS = ("gba_create", "gba_destroy", "gba_set_scoring", "gba_submit", "gba_wait",
-           "gba_submit_device", "gba_submit_device_noalloc", "gba_host_alloc", "gba_host_free", "gba_set_reference", "gba_get_timing", "gba_last_hip_error", "gba_strerror", "gba_version")
+           "gba_submit_device", "gba_submit_device_noalloc", "gba_sdp_device", "gba_host_alloc", "gba_host_free", "gba_set_reference", "gba_get_timing", "gba_last_hip_error", "gba_strerror", "gba_version")
 
 _lib = None
 
@@ -116,6 +126,7 @@ def lib():
         L.gba_host_free.restype = None
         L.gba_submit_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Results)]
         L.gba_submit_device_noalloc.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Results)]
+        L.gba_sdp_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(SdpParams), C.POINTER(Guides)]
         L.gba_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.gba_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         L.gba_last_hip_error.argtypes = [C.c_void_p]

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (BLOCK_DT, PAIR_RESULT_DT, Batch, Config, GbaError, Results, Scoring, Timing)
+from ._lib import (BLOCK_DT, PAIR_RESULT_DT, Batch, Config, GbaError, Guides, Results, Scoring, SdpParams, Timing)
 
 
 def make_scoring(match=-5, mismatch=6, n_score=0, ins=5, dele=4, indel=5, band=10, max_band=250,
@@ -194,6 +194,33 @@ class Context:
         rc, needed = self.wait_host()
         return pairs, blocks[:min(needed, int(blocks_capacity))], ops[:min(self.cigar_needed, len(ops))], off, rc
 
+    # ---- guide production (device-resident tensors)
+    def sdp_device(self, dbatch, params, blocks_capacity=None):
+        """gba_sdp_device on a device batch (as for refine_device; its "blocks", "blk_off", "n_blk"
+        are not read).  Returns a dict of torch tensors on the batch's device: status (int32),
+        chain_score (int32), n_blk (int32, bit pattern of uint32), blk_off (int64), blocks (int32
+        [capacity, 3]), plus "rc" and "blocks_needed".  n_blk / blk_off / blocks can replace the
+        batch's own guide entries for refine_device."""
+        import torch
+        n = int(dbatch["n_pairs"])
+        dev = dbatch["q_arena"].device
+        if blocks_capacity is None:
+            blocks_capacity = max(1, int(dbatch["q_arena"].numel()) // 8 + n)
+        g = {"status": torch.zeros(n, dtype=torch.int32, device=dev), "chain_score": torch.zeros(n, dtype=torch.int32, device=dev),
+             "n_blk": torch.zeros(n, dtype=torch.int32, device=dev), "blk_off": torch.zeros(n, dtype=torch.int64, device=dev),
+             "blocks": torch.zeros((int(blocks_capacity), 3), dtype=torch.int32, device=dev)}
+        ta = dbatch.get("t_arena")
+        trc = dbatch.get("t_rc")
+        b = Batch(n, dbatch["q_arena"].data_ptr(), dbatch["q_off"].data_ptr(), dbatch["q_len"].data_ptr(),
+                  ta.data_ptr() if ta is not None else None, dbatch["t_off"].data_ptr(), dbatch["t_len"].data_ptr(),
+                  None, None, None, dbatch["q_arena"].numel(), ta.numel() if ta is not None else 0, 0,
+                  trc.data_ptr() if trc is not None else None)
+        r = Guides(g["status"].data_ptr(), g["chain_score"].data_ptr(), g["n_blk"].data_ptr(), g["blk_off"].data_ptr(),
+                   g["blocks"].data_ptr(), int(blocks_capacity), 0)
+        g["rc"] = self._check(self._L.gba_sdp_device(self._h, C.byref(b), C.byref(params), C.byref(r)), allow=(_lib.E_NOSPACE,))
+        g["blocks_needed"] = int(r.blocks_needed)
+        return g
+
     # ---- device-resident tensors
     def refine_device(self, dbatch, out_pairs, out_blocks, no_alloc=False, cigar=None):
         """dbatch: dict of torch CUDA tensors with the same keys as a host batch (uint8 arenas;
@@ -222,6 +249,12 @@ class Context:
         rc = self._check(fn(self._h, C.byref(b), C.byref(r)), allow=(_lib.E_NOSPACE,))
         self.cigar_needed = int(r.cigar_needed)
         return rc, int(r.blocks_needed)
+
+
+def make_sdp_params(tuple_size=11, ins=5, dele=10, match=5, max_fragments=1024):
+    """gba_sdp_params with BLASR's defaults: sdpTupleSize 11, sdpIns 5, sdpDel 10
+    (iblasr/MappingParameters.h:220-222), a reward of 5 per anchored base (minus the match score)."""
+    return SdpParams(tuple_size, ins, dele, match, max_fragments)
 
 
 class HostPipeline:

@@ -1662,6 +1662,314 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_ops(Dev d, uint64_t *carry, uin
     if (threadIdx.x == 0) { off[d.n] = c0 + tot; *carry = c0 + tot; }
 }
 
+// ================================================================ guide production
+// The step in front of the refine stage: exact k-mer matches between a read and its reference
+// window, chained by sparse dynamic programming into the increasing list of gap-free blocks that
+// the guided alignment follows (SDPAlign(..., Local) at iblasr/BlasrAlignImpl.hpp:980-987).
+//   fragments  the maximal exact matches of length >= k between ACGT bases (a run of overlapping
+//              k-mer hits on one diagonal is one fragment), ordered by (query start, target start)
+//   chain      score(f) = match * len(f) + max(0, max over earlier fragments p of
+//              score(p) - drift penalty - match * overlap), where drift = change of diagonal
+//              (del per target base gained, ins per query base gained) and overlap = the bases
+//              of p's tail that reach past f's start in either sequence (p is shortened by them;
+//              something of p must remain); ties go to the earliest p; the best score anywhere
+//              (earliest on ties) ends the chain
+// One workgroup of 256 threads per pair.  Both sequences are packed into LDS (2 bits per base plus
+// a bit pair that marks letters outside ACGT and positions past the end); the target is indexed
+// SDP_TILE positions at a time in an LDS hash table keyed by k-mer whose entries head a linked
+// list of the tile's positions with that k-mer, and every query position is looked up.  A hit
+// that continues a match from the previous diagonal cell is dropped, the others are extended 16
+// bases at a time and become fragments.  The fragments are sorted in LDS (bitonic), then one wave
+// chains them: 64 fragments per round, every lane scanning all earlier fragments (uniform LDS
+// reads), the 64 of the round settling among themselves lane by lane.
+constexpr uint32_t SDP_THREADS = 256;
+typedef uint32_t u32x4u1 __attribute__((ext_vector_type(4), aligned(1)));
+
+struct SdpConst {
+    uint32_t k, kmask;            // tuple size, mask of a k-mer (2k bits)
+    int32_t ins, del, match;
+    uint32_t max_fragments, cap;  // cap: max_fragments rounded up to a power of two (sort capacity)
+    uint32_t hit_limit;           // more k-mer hits than this in one pair: too repetitive
+    uint32_t tile, slots_log2;    // target positions indexed at a time; log2 of the hash slots (= 2 * tile)
+    uint32_t qwords, twords;      // dwords of a packed sequence (including two pad words)
+};
+
+// query codes (code + 1, 6 for letters outside ACGT) of the whole read, 32 pad bytes behind it
+__global__ __launch_bounds__(256) void k_pack_q(Dev d, uint8_t *qcodes)
+{
+    const uint32_t p = blockIdx.x;
+    if (d.status[p] != GBA_PAIR_OK) return;
+    const uint32_t Q = d.Q[p];
+    const uint8_t *q = d.q_arena + d.q_off[p] + d.qS[p];
+    uint8_t *qc = qcodes + align16(d.row_off[p] + 48ull * p);
+    for (uint32_t x0 = 4 * threadIdx.x; x0 < Q + 32; x0 += 4 * blockDim.x) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            uint32_t c = 6u;
+            if (x0 + x < Q) { c = base_code(q[x0 + x]) + 1u; if (c == 5u) c = 6u; }
+            w |= c << (8 * x);
+        }
+        *(uint32_t *)(qc + x0) = w;
+    }
+}
+
+// largest query / target length of the pairs that are still OK (into two spare words of the plan)
+__global__ void k_sdp_max(Dev d)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.n || d.status[p] != GBA_PAIR_OK) return;
+    atomicMax(&d.plan->cls_count[0], d.Q[p]);
+    atomicMax(&d.plan->cls_count[1], d.T[p]);
+}
+
+// 16 bases (32 bits) of a packed array starting at base `pos`
+__device__ __forceinline__ uint32_t window16(const uint32_t *pk, uint32_t pos)
+{
+    const uint32_t w = pos >> 4, b = (pos & 15u) * 2u;
+    const uint64_t v = (uint64_t)pk[w] | (uint64_t)pk[w + 1] << 32;
+    return (uint32_t)(v >> b);
+}
+
+__device__ __forceinline__ bool cas16(uint32_t *tab32, uint32_t h, uint32_t expect, uint32_t val)
+{
+    uint32_t *w = tab32 + (h >> 1);
+    const uint32_t sh = (h & 1u) * 16u;
+    uint32_t old = *(volatile uint32_t *)w;
+    for (;;) {
+        if (((old >> sh) & 0xffffu) != expect) return false;
+        const uint32_t nw = (old & ~(0xffffu << sh)) | val << sh;
+        const uint32_t prev = atomicCAS(w, old, nw);
+        if (prev == old) return true;
+        old = prev;
+    }
+}
+
+__global__ __launch_bounds__(SDP_THREADS) void k_sdp(Dev d, SdpConst sc, const uint8_t *qcodes, int32_t *out_status,
+                                                       int32_t *out_score, uint32_t *out_nblk, gba_block *chains)
+{
+    extern __shared__ uint32_t smem[];
+    __shared__ uint32_t s_nfrag, s_hits, s_nchain;
+    const uint32_t p = blockIdx.x, tid = threadIdx.x;
+    const uint32_t SLOTS = 1u << sc.slots_log2;
+    // LDS: hash heads (u16 x SLOTS) | next (u16 x tile) | fragments (4 dwords x cap) | query bases, query marks, target bases, target marks
+    uint32_t *tab32 = smem;
+    unsigned short *nxt = (unsigned short *)(smem + SLOTS / 2);
+    uint4 *F = (uint4 *)(((uintptr_t)(smem + SLOTS / 2 + sc.tile / 2) + 15u) & ~(uintptr_t)15u);   // .x = query start << 16 | target start, .y = length, .z = score, .w = predecessor
+    uint32_t *qp = (uint32_t *)(F + sc.cap), *qs = qp + sc.qwords, *tp = qs + sc.qwords, *ts = tp + sc.twords;
+
+    int st = d.status[p];
+    const uint32_t Q = d.Q[p], T = d.T[p];
+    if (st == GBA_PAIR_OK && T > 65535u) st = GBA_PAIR_TOO_LONG;          // (the query is limited to 65 535 bases by k_meta)
+    if (st == GBA_PAIR_OK && (Q < sc.k || T < sc.k)) st = GBA_PAIR_EMPTY_GUIDE;
+    if (st != GBA_PAIR_OK) {                                              // uniform over the workgroup
+        if (tid == 0) { out_status[p] = st; out_score[p] = 0; out_nblk[p] = 0; }
+        return;
+    }
+    if (tid == 0) { s_nfrag = 0; s_hits = 0; s_nchain = 0; }
+    // ---- pack both sequences: 16 bases per dword, and a dword of marks (01 per base that is no ACGT base of the sequence)
+    {
+        const uint8_t *qc = qcodes + align16(d.row_off[p] + 48ull * p);
+        const uint8_t *tc = d.tcodes + tc_offset(d, p) + 1;
+        for (uint32_t w = tid; w < sc.qwords + sc.twords; w += SDP_THREADS) {
+            const bool isq = w < sc.qwords;
+            const uint32_t ww = isq ? w : w - sc.qwords, len = isq ? Q : T;
+            uint32_t bases = 0, marks = 0x55555555u;
+            if (ww * 16u < len) {
+                const u32x4u1 raw = *(const u32x4u1 *)((isq ? qc : tc) + 16u * ww);
+                marks = 0;
+#pragma unroll
+                for (int x = 0; x < 16; x++) {
+                    const uint32_t c = (raw[x >> 2] >> (8 * (x & 3))) & 0xffu;      // code + 1: 1..4, above that no base
+                    const bool ok = c <= 4u && ww * 16u + (uint32_t)x < len;
+                    bases |= (ok ? c - 1u : 0u) << (2 * x);
+                    marks |= (ok ? 0u : 1u) << (2 * x);
+                }
+            }
+            (isq ? qp : tp)[ww] = bases;
+            (isq ? qs : ts)[ww] = marks;
+        }
+    }
+    const uint32_t kbits = 2u * sc.k;
+    const uint32_t kmark = (uint32_t)((1ull << kbits) - 1ull) & 0x55555555u;
+    const uint32_t hshift = 32u - sc.slots_log2;
+    // ---- matches, one tile of the target at a time
+    for (uint32_t tile0 = 0; tile0 + sc.k <= T; tile0 += sc.tile) {
+        __syncthreads();
+        for (uint32_t i = tid; i < SLOTS / 2; i += SDP_THREADS) tab32[i] = 0;
+        __syncthreads();
+        const uint32_t tend = min(tile0 + sc.tile, T - sc.k + 1u);        // k-mers start in [tile0, tend)
+        for (uint32_t y = tile0 + tid; y < tend; y += SDP_THREADS) {
+            if (window16(ts, y) & kmark) continue;                        // a letter outside ACGT in the k-mer
+            const uint32_t km = window16(tp, y) & sc.kmask;
+            const uint32_t yl = y - tile0, y1 = yl + 1u;
+            uint32_t h = (km * 0x9E3779B1u) >> hshift;
+            for (;;) {
+                const uint32_t v = (tab32[h >> 1] >> ((h & 1u) * 16u)) & 0xffffu;
+                if (v == 0u) {
+                    nxt[yl] = 0;
+                    if (cas16(tab32, h, 0u, y1)) break;
+                    continue;                                             // somebody took the slot: look at it again
+                }
+                if ((window16(tp, tile0 + v - 1u) & sc.kmask) == km) {    // the list of this k-mer: push in front
+                    nxt[yl] = (unsigned short)v;
+                    if (cas16(tab32, h, v, y1)) break;
+                    continue;
+                }
+                h = (h + 1u) & (SLOTS - 1u);
+            }
+        }
+        __syncthreads();
+        for (uint32_t x = tid; x + sc.k <= Q; x += SDP_THREADS) {
+            if (*(volatile uint32_t *)&s_hits > sc.hit_limit) break;
+            if (window16(qs, x) & kmark) continue;
+            const uint32_t km = window16(qp, x) & sc.kmask;
+            uint32_t h = (km * 0x9E3779B1u) >> hshift, v;
+            for (;;) {
+                v = (tab32[h >> 1] >> ((h & 1u) * 16u)) & 0xffffu;
+                if (v == 0u || (window16(tp, tile0 + v - 1u) & sc.kmask) == km) break;
+                h = (h + 1u) & (SLOTS - 1u);
+            }
+            uint32_t hits = 0;
+            for (; v; v = nxt[v - 1u]) {
+                const uint32_t y = tile0 + v - 1u;
+                hits++;
+                // the start of its run? (the cell one step back on the diagonal is no match)
+                if (x > 0u && y > 0u) {
+                    const uint32_t a = window16(qp, x - 1u), b = window16(tp, y - 1u), m = window16(qs, x - 1u) | window16(ts, y - 1u);
+                    if ((((a ^ b) | m) & 3u) == 0u) continue;
+                }
+                uint32_t len = sc.k;
+                for (;;) {
+                    const uint32_t a = window16(qp, x + len), b = window16(tp, y + len), m = window16(qs, x + len) | window16(ts, y + len);
+                    const uint32_t df = a ^ b;
+                    const uint32_t bad = ((df | df >> 1) | m) & 0x55555555u;
+                    if (bad) { len += (uint32_t)__builtin_ctz(bad) >> 1; break; }
+                    len += 16u;
+                }
+                const uint32_t at = atomicAdd(&s_nfrag, 1u);
+                if (at < sc.cap) F[at] = make_uint4(x << 16 | y, len, 0u, 0xffffu);
+            }
+            if (hits) atomicAdd(&s_hits, hits);
+        }
+    }
+    __syncthreads();
+    const uint32_t n = s_nfrag;
+    if (n > sc.max_fragments || s_hits > sc.hit_limit || n == 0u) {
+        if (tid == 0) { out_status[p] = n == 0u && s_hits <= sc.hit_limit ? GBA_PAIR_EMPTY_GUIDE : GBA_PAIR_TOO_MANY; out_score[p] = 0; out_nblk[p] = 0; }
+        return;
+    }
+    // ---- sort by (query start, target start)
+    uint32_t P2 = 1;
+    while (P2 < n) P2 <<= 1;
+    for (uint32_t i = n + tid; i < P2; i += SDP_THREADS) F[i] = make_uint4(0xffffffffu, 0u, 0u, 0xffffu);
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1)
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < P2; i += SDP_THREADS) {
+                const uint32_t o = i ^ j;
+                if (o > i) {
+                    const uint4 a = F[i], b = F[o];
+                    if ((a.x > b.x) == ((i & k2) == 0u)) { F[i] = b; F[o] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // ---- chain (one wave)
+    if (tid < 64u) {
+        const int32_t M = sc.match, INS = sc.ins, DEL = sc.del;
+        int32_t best_all = 0; uint32_t end = 0;
+        for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+            const uint32_t f = b0 + tid;
+            const bool live = f < n;
+            const uint4 me = live ? F[f] : make_uint4(0u, 0u, 0u, 0u);
+            const int32_t x = (int32_t)(me.x >> 16), y = (int32_t)(me.x & 0xffffu), diag = y - x;
+            int32_t best = 0; uint32_t bp = 0xffffu;
+            auto relax = [&](uint4 pr, uint32_t pidx, bool allowed) {
+                const int32_t px = (int32_t)(pr.x >> 16), py = (int32_t)(pr.x & 0xffffu), pl = (int32_t)pr.y;
+                const int32_t o = max(max(px + pl - x, py + pl - y), 0);
+                const int32_t dd = diag - (py - px);
+                const int32_t g = (int32_t)pr.z - max(dd * DEL, -dd * INS) - o * M;
+                if (allowed && o < pl && g > best) { best = g; bp = pidx; }
+            };
+            for (uint32_t q0 = 0; q0 < b0; q0++) relax(F[q0], q0, true);
+            // the fragments of this round among themselves: lane j is final once lanes 0..j-1 have been offered to it
+            const uint32_t lim = min(64u, n - b0);
+            for (uint32_t j = 0; j < lim; j++) {
+                const int32_t mine = (int32_t)me.y * M + best;
+                uint4 pr;
+                pr.x = (uint32_t)__builtin_amdgcn_readlane((int32_t)me.x, j);
+                pr.y = (uint32_t)__builtin_amdgcn_readlane((int32_t)me.y, j);
+                pr.z = (uint32_t)__builtin_amdgcn_readlane(mine, j);
+                relax(pr, b0 + j, tid > j);
+            }
+            if (live) {
+                const int32_t sc_f = (int32_t)me.y * M + best;
+                F[f].z = (uint32_t)sc_f; F[f].w = bp;
+            }
+            // best end so far: the highest score, the earliest fragment on ties
+            int32_t v = live ? (int32_t)me.y * M + best : 0;
+            uint32_t vi = f;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int32_t ov = __shfl_xor(v, o, 64);
+                const uint32_t oi = (uint32_t)__shfl_xor((int)vi, o, 64);
+                if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
+            }
+            if (v > best_all) { best_all = v; end = vi; }
+        }
+        // trace back (one lane), the chain's fragment numbers go where the scores were, last first
+        if (tid == 0) {
+            uint32_t cnt = 0;
+            for (uint32_t f = end; f != 0xffffu; f = F[f].w) cnt++;
+            uint32_t i = cnt;
+            for (uint32_t f = end; f != 0xffffu;) { const uint32_t nf = F[f].w; F[--i].z = f; f = nf; }
+            s_nchain = cnt;
+            out_status[p] = GBA_PAIR_OK; out_score[p] = best_all; out_nblk[p] = cnt;
+        }
+    }
+    __syncthreads();
+    const uint32_t nc = s_nchain;
+    gba_block *outb = chains + (uint64_t)p * sc.max_fragments;
+    for (uint32_t i = tid; i < nc; i += SDP_THREADS) {
+        const uint4 a = F[F[i].z];
+        uint32_t len = a.y;
+        if (i + 1 < nc) {
+            const uint4 b = F[F[i + 1].z];
+            const int32_t ox = (int32_t)((a.x >> 16) + a.y) - (int32_t)(b.x >> 16), oy = (int32_t)((a.x & 0xffffu) + a.y) - (int32_t)(b.x & 0xffffu);
+            const int32_t o = max(max(ox, oy), 0);
+            len -= (uint32_t)o;
+        }
+        gba_block bl;
+        bl.q_pos = a.x >> 16; bl.t_pos = a.x & 0xffffu; bl.length = len;
+        outb[i] = bl;
+    }
+}
+
+// counts -> offsets (single block), carried from part to part like k_scan1
+__global__ __launch_bounds__(SCAN_T) void k_scan_cnt(const uint32_t *cnt, uint64_t *off, uint32_t n, uint64_t *carry)
+{
+    __shared__ uint64_t sm[17];
+    const uint64_t c0 = *carry;
+    __syncthreads();
+    const uint64_t tot = scan_array(cnt, off, n, sm);
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) off[p] += c0;
+    if (threadIdx.x == 0) *carry = c0 + tot;
+}
+
+// the chains of a part packed into the caller's arena
+__global__ __launch_bounds__(256) void k_sdp_emit(const gba_block *chains, uint32_t stride, const uint32_t *nblk, const uint64_t *off,
+                                                  gba_block *out, uint64_t capacity, int32_t *status)
+{
+    const uint32_t p = blockIdx.x, nb = nblk[p];
+    const uint64_t o = off[p];
+    if (nb == 0) return;
+    if (o + nb > capacity) { if (threadIdx.x == 0) status[p] = GBA_PAIR_NOSPACE; return; }
+    const gba_block *src = chains + (uint64_t)p * stride;
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) out[o + i] = src[i];
+}
+
 // ================================================================ host side
 struct Buf {
     void *ptr = nullptr;
@@ -1707,6 +2015,8 @@ struct gba_ctx {
     int last_hip = 0;
     bool have_scoring = false;
     bool lds_attr_set = false;       // the fill kernels' dynamic-LDS limit has been raised on this device
+    bool sdp_attr_set = false;       // the same for k_sdp
+    uint32_t sdp_tile_max = 8192;    // target positions indexed at a time by k_sdp, at most (env GBA_SDP_TILE; power of two, 1024..16384)
     gba_scoring sc;
     FillConst fc;
     TbConst tbc;
@@ -2212,6 +2522,92 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
     return out->blocks_needed > out->blocks_capacity || out->cigar_needed > out->cigar_capacity ? GBA_E_NOSPACE : GBA_OK;
 }
 
+// Guide production for a batch whose inputs and outputs are device pointers, in parts of at most
+// SDP_PART pairs on the ctx's main stream (the chains of a part wait in device scratch, max_fragments
+// blocks per pair, until the part's block offsets are known).
+constexpr uint32_t SDP_PART = 32768;
+
+int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides *out)
+{
+    const uint32_t n = b->n_pairs;
+    out->blocks_needed = 0;
+    if (n == 0) return GBA_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    Slot &sl = c->slot[0];
+    hipStream_t s = sl.s;
+    const uint32_t per = n < SDP_PART ? n : SDP_PART;
+    for (int i = 0; i < 14; i++) { int rc = ensure(c, c->b_pair32[i], (size_t)per * 4); if (rc) return rc; }
+    for (int i = 0; i < 5; i++) { int rc = ensure(c, c->b_pair64[i], (size_t)per * 8); if (rc) return rc; }
+    { int rc = ensure(c, c->b_needed, 16); if (rc) return rc; }
+    { int rc = ensure(c, sl.b_plan, sizeof(Plan)); if (rc) return rc; }
+    uint64_t *needed = (uint64_t *)c->b_needed.ptr;
+    HIPCHK(c, hipMemsetAsync(needed, 0, 16, s));
+    SdpConst k;
+    k.k = (uint32_t)sp->tuple_size; k.kmask = (uint32_t)((1ull << (2 * sp->tuple_size)) - 1ull);
+    k.ins = sp->ins; k.del = sp->del; k.match = sp->match;
+    k.max_fragments = sp->max_fragments;
+    k.cap = 64; while (k.cap < k.max_fragments) k.cap <<= 1;
+    k.hit_limit = 64u * k.max_fragments;
+    if (!c->sdp_attr_set) {
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_sdp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));   // the kernel has a few static words too
+        c->sdp_attr_set = true;
+    }
+    for (uint32_t first = 0; first < n; first += per) {
+        const uint32_t cnt = n - first < per ? n - first : per;
+        Dev d;
+        memset(&d, 0, sizeof(d));
+        d.n = cnt;
+        d.q_arena = b->q_arena; d.t_arena = b->t_arena; d.t_rc = b->t_rc ? b->t_rc + first : nullptr;
+        d.q_arena_bytes = b->q_arena_bytes; d.t_arena_bytes = b->t_arena_bytes;
+        if (!d.t_arena) { d.t_arena = (const uint8_t *)c->b_ref.ptr; d.t_arena_bytes = c->ref_len; }
+        d.q_off = b->q_off + first; d.t_off = b->t_off + first; d.q_len = b->q_len + first; d.t_len = b->t_len + first;
+        d.status = (int32_t *)c->b_pair32[0].ptr;
+        d.qS = (uint32_t *)c->b_pair32[1].ptr; d.tS = (uint32_t *)c->b_pair32[2].ptr;
+        d.Q = (uint32_t *)c->b_pair32[3].ptr; d.T = (uint32_t *)c->b_pair32[4].ptr;
+        d.rows = (uint32_t *)c->b_pair32[5].ptr; d.cols = (uint32_t *)c->b_pair32[6].ptr;
+        d.span = (uint32_t *)c->b_pair32[7].ptr; d.lo_last = (uint32_t *)c->b_pair32[8].ptr;
+        d.cls = (uint32_t *)c->b_pair32[9].ptr; d.order = (uint32_t *)c->b_pair32[10].ptr;
+        d.dp_score = (int32_t *)c->b_pair32[11].ptr; d.wcap = (uint32_t *)c->b_pair32[12].ptr; d.recdw = (uint32_t *)c->b_pair32[13].ptr;
+        d.row_off = (uint64_t *)c->b_pair64[0].ptr; d.col_off = (uint64_t *)c->b_pair64[1].ptr;
+        d.rec_off = (uint64_t *)c->b_pair64[2].ptr; d.ncells = (uint64_t *)c->b_pair64[3].ptr;
+        d.word_off = (uint64_t *)c->b_pair64[4].ptr;
+        d.plan = (Plan *)sl.b_plan.ptr;
+        // the whole read against the whole window: the k-band mode of k_meta with no limit on the length difference
+        HIPCHK(c, hipMemsetAsync(d.plan, 0, sizeof(Plan), s));
+        hipLaunchKernelGGL(k_meta, dim3((cnt + 255) / 256), dim3(256), 0, s, d, (int)GBA_MODE_KBAND, 0x7fffffff, 0u, 0u, 0xffffffffu);
+        hipLaunchKernelGGL(k_scan3, dim3(1), dim3(SCAN_T), 0, s, d);
+        hipLaunchKernelGGL(k_sdp_max, dim3((cnt + 255) / 256), dim3(256), 0, s, d);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(sl.h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        const uint64_t rows = sl.h_plan->total_rows, cols = sl.h_plan->total_cols;
+        const uint32_t maxQ = sl.h_plan->cls_count[0], maxT = sl.h_plan->cls_count[1] > 65535u ? 65535u : sl.h_plan->cls_count[1];
+        { int rc = ensure(c, sl.b_tc, (size_t)(cols + 48ull * cnt + 64 + 2 * ARENA_SLACK)); if (rc) return rc; }
+        { int rc = ensure(c, sl.b_rec, (size_t)(rows + 48ull * cnt + 64)); if (rc) return rc; }
+        { int rc = ensure(c, sl.b_blk, (size_t)cnt * k.max_fragments * sizeof(gba_block) + 16); if (rc) return rc; }
+        d.tcodes = (uint8_t *)sl.b_tc.ptr + ARENA_SLACK;
+        uint8_t *qcodes = (uint8_t *)sl.b_rec.ptr;
+        hipLaunchKernelGGL(k_pack, dim3(cnt), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k_pack_q, dim3(cnt), dim3(256), 0, s, d, qcodes);
+        // the target is indexed a tile at a time: a tile of half the hash slots, sized to the longest window (up to SDP_TILE_MAX)
+        k.tile = 1024; while (k.tile < maxT && k.tile < c->sdp_tile_max) k.tile <<= 1;
+        k.slots_log2 = 1; while ((1u << k.slots_log2) < 2 * k.tile) k.slots_log2++;
+        k.qwords = maxQ / 16 + 3; k.twords = maxT / 16 + 3;
+        const size_t lds = ((size_t)(1u << k.slots_log2) / 2 + k.tile / 2 + (size_t)k.cap * 4 + 2 * (size_t)(k.qwords + k.twords)) * 4 + 16;
+        if (lds > 160 * 1024 - 256) return GBA_E_UNSUPPORTED;
+        hipLaunchKernelGGL(k_sdp, dim3(cnt), dim3(SDP_THREADS), lds, s, d, k, (const uint8_t *)qcodes, out->status + first, out->chain_score + first,
+                           out->n_blk + first, (gba_block *)sl.b_blk.ptr);
+        hipLaunchKernelGGL(k_scan_cnt, dim3(1), dim3(SCAN_T), 0, s, (const uint32_t *)(out->n_blk + first), out->blk_off + first, cnt, needed);
+        hipLaunchKernelGGL(k_sdp_emit, dim3(cnt), dim3(256), 0, s, (const gba_block *)sl.b_blk.ptr, k.max_fragments,
+                           (const uint32_t *)(out->n_blk + first), (const uint64_t *)(out->blk_off + first), out->blocks, out->blocks_capacity, out->status + first);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_needed, needed, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    out->blocks_needed = c->h_needed[0];
+    return out->blocks_needed > out->blocks_capacity ? GBA_E_NOSPACE : GBA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2236,6 +2632,7 @@ const char *gba_strerror(int code)
     case GBA_PAIR_END_OUT_OF_BAND: return "pair: end cell outside the k-band";
     case GBA_PAIR_TOO_WIDE: return "pair: band row too wide";
     case GBA_PAIR_TOO_LONG: return "pair: too many rows or columns";
+    case GBA_PAIR_TOO_MANY: return "pair: too many k-mer matches to chain";
     default: return "unknown code";
     }
 }
@@ -2265,6 +2662,10 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
         if (const char *e = getenv("GBA_PART_PAIRS")) c->part_pairs = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_WAVE_PAIRS")) c->wave_pairs = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_WAVE_PAIRS_AFFINE")) c->wave_pairs_affine = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char *e = getenv("GBA_SDP_TILE")) {
+            const uint32_t v = (uint32_t)strtoul(e, nullptr, 10);
+            if (v >= 1024 && v <= 16384 && (v & (v - 1)) == 0) c->sdp_tile_max = v;
+        }
         for (int h = 0; h < NSLOT && !rc; h++) {
             Slot &sl = c->slot[h];
             if (h == 0) sl.s = c->stream;
@@ -2578,6 +2979,18 @@ void gba_host_free(gba_ctx *c, void *ptr)
             c->host_allocs.erase(c->host_allocs.begin() + (long)i);
             return;
         }
+}
+
+int gba_sdp_device(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides *out)
+{
+    if (!c || !b || !sp || !out) return GBA_E_INVALID;
+    if (c->in_flight) return GBA_E_STATE;
+    if (sp->tuple_size < 4 || sp->tuple_size > 15 || sp->match < 1 || sp->match > 127 || sp->ins < 0 || sp->ins > 127 ||
+        sp->del < 0 || sp->del > 127 || sp->max_fragments < 1 || sp->max_fragments > 4096) return GBA_E_UNSUPPORTED;
+    if (b->n_pairs && (!b->q_arena || !b->q_off || !b->t_off || !b->q_len || !b->t_len)) return GBA_E_INVALID;
+    if (b->n_pairs && (!out->status || !out->chain_score || !out->n_blk || !out->blk_off || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
+    if (b->n_pairs && !b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
+    return run_sdp(c, b, sp, out);
 }
 
 int gba_set_reference(gba_ctx *c, const uint8_t *ref, uint64_t len)

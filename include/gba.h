@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GBA_VERSION 310   /* major*10000 + minor*100 + patch */
+#define GBA_VERSION 320   /* major*10000 + minor*100 + patch */
 
 /* return codes of the entry points */
 enum {
@@ -44,9 +44,12 @@ enum {
     GBA_PAIR_NOSPACE = 4,          /* blocks of this pair did not fit the caller's arena */
     GBA_PAIR_END_OUT_OF_BAND = 5,  /* k-band: |t_len - q_len| > k */
     GBA_PAIR_TOO_WIDE = 6,         /* a band row wider than the kernels support (linear, k-band: 1023 cells or a shift of 1023; affine: the same) */
-    GBA_PAIR_TOO_LONG = 7          /* more DP rows or columns than the kernels support (65535 rows, affine 32767; 2^20 columns),
+    GBA_PAIR_TOO_LONG = 7,         /* more DP rows or columns than the kernels support (65535 rows, affine 32767; 2^20 columns),
                                       or rows x (128 + largest |substitution, insertion cost|) + columns x |deletion cost|
-                                      reaches 2^24 (affine 2^23): the scores would not fit the kernels' cell words */
+                                      reaches 2^24 (affine 2^23): the scores would not fit the kernels' cell words;
+                                      gba_sdp_device: a read or window of more than 65535 bases */
+    GBA_PAIR_TOO_MANY = 8          /* gba_sdp_device only: more maximal matches than max_fragments, or more than
+                                      64 x max_fragments k-mer hits (a repeat): no guide is produced */
 };
 
 enum { GBA_MODE_LINEAR = 0,   /* replaces GuidedAlign,       BlasrUtilsImpl.hpp:713-716, :727-730 */
@@ -237,6 +240,42 @@ int gba_submit_device(gba_ctx *ctx, const gba_batch *dev_batch, gba_results *dev
  * time on one GPU race; calls one after the other are independent (nothing is carried over). */
 #define GBA_NOALLOC_SCRATCH_BYTES (64u << 20)
 int gba_submit_device_noalloc(gba_ctx *ctx, const gba_batch *dev_batch, gba_results *dev_out);
+
+/* ---- guide production: the step in front of the refine stage -------------------------------
+ * Replaces SDPAlign(alignment->qAlignedSeq, alignment->tAlignedSeq, distScoreFn, sdpTupleSize,
+ * params.sdpIns, params.sdpDel, params.indelRate*3, *alignment, mappingBuffers, Local, ...)
+ * (iblasr/BlasrAlignImpl.hpp:980-987), whose result is alignment->blocks, the guide of the refine
+ * stage: exact k-mer matches between each read and its window are chained into an increasing list
+ * of gap-free blocks.  Fragments are the maximal exact matches of at least tuple_size ACGT bases;
+ * a chain scores match per anchored base, minus ins / del per base by which consecutive fragments
+ * change diagonal, minus match per base of overlap between consecutive fragments (the earlier one
+ * is shortened); the best chain ending anywhere is returned (Local).  SDPAlign itself is libcpp
+ * code that the reference tree does not hold: this is the published scheme as an exact optimum,
+ * not a transcription (no detailed second pass with a smaller tuple, no fastSDP pruning). */
+typedef struct {
+    int32_t tuple_size;         /* params.sdpTupleSize (11, iblasr/MappingParameters.h:222); 4..15 */
+    int32_t ins, del;           /* params.sdpIns (5), params.sdpDel (10), :220-221; 0..127 */
+    int32_t match;              /* reward per anchored base: minus the match score of the scorer (5); 1..127 */
+    uint32_t max_fragments;     /* fragments (and blocks) per pair, at most; 1..4096 */
+} gba_sdp_params;
+
+/* All pointers of gba_guides are device pointers.  n_blk, blk_off and blocks have the layout of
+ * gba_batch: they can be handed to gba_submit_device as the guides of the same batch. */
+typedef struct {
+    int32_t *status;            /* n_pairs: GBA_PAIR_OK; GBA_PAIR_EMPTY_GUIDE (no match of tuple_size bases); GBA_PAIR_BAD_GUIDE (a
+                                   slice outside its arena); GBA_PAIR_TOO_LONG; GBA_PAIR_TOO_MANY; GBA_PAIR_NOSPACE */
+    int32_t *chain_score;       /* n_pairs */
+    uint32_t *n_blk;            /* n_pairs: blocks of the chain, 0 unless status is OK (or NOSPACE) */
+    uint64_t *blk_off;          /* n_pairs: first block of the pair in `blocks`, packed in input order */
+    gba_block *blocks;          /* positions relative to the starts of the read and of the window */
+    uint64_t blocks_capacity;
+    uint64_t blocks_needed;     /* out */
+} gba_guides;
+
+/* batch: q_arena, q_off, q_len, t_arena (or the ctx reference), t_off, t_len, t_rc are used; blocks,
+ * blk_off, n_blk are ignored.  Returns when the guides are complete.  GBA_E_NOSPACE: blocks_needed >
+ * blocks_capacity (pairs that did not fit have GBA_PAIR_NOSPACE). */
+int gba_sdp_device(gba_ctx *ctx, const gba_batch *device_batch, const gba_sdp_params *params, gba_guides *device_out);
 
 /* Keeps a copy of the reference (genome, ASCII; `ref` is a host pointer) in device
  * memory for batches whose t_arena is NULL; len == 0 drops it.  Replaces the

@@ -52,7 +52,7 @@ RESULT_DT = np.dtype([
 
 def build(force=False):
     if force or not os.path.exists(_SO) or \
-            os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "gba_oracle.c")):
+            os.path.getmtime(_SO) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("gba_oracle.c", "sdp_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -71,6 +71,8 @@ def lib():
         _lib.gbo_full_dp_score.restype = C.c_int
         _lib.gbo_align_batch.restype = C.c_int
         _lib.gbo_align_batch_mt.restype = C.c_int
+        _lib.sdo_chain.restype = C.c_int
+        _lib.sdo_chain_batch.restype = C.c_int
     return _lib
 
 
@@ -207,3 +209,51 @@ def align_batch_mt(batch, params, threads, seconds=0.0, first=0, count=None):
                              C.c_int(int(threads)), C.c_double(float(seconds)),
                              C.byref(pairs_done), C.byref(cells_done), C.byref(elapsed))
     return results, out, out_off, int(pairs_done.value), int(cells_done.value), float(elapsed.value)
+
+
+# ---- the guide producer (sdp_oracle.c)
+SDP_OK, SDP_EMPTY, SDP_TOO_LONG, SDP_TOO_MANY = 0, 1, 7, 8
+
+
+class SdpParams(C.Structure):
+    _fields_ = [("k", C.c_int32), ("ins", C.c_int32), ("dele", C.c_int32), ("match", C.c_int32),
+                ("max_fragments", C.c_uint32)]
+
+
+def make_sdp_params(k=11, ins=5, dele=10, match=5, max_fragments=4096):
+    """BLASR's defaults: sdpTupleSize 11, sdpIns 5, sdpDel 10 (iblasr/MappingParameters.h:220-222),
+    reward per anchored base = minus the match score of the distance matrix."""
+    return SdpParams(k, ins, dele, match, max_fragments)
+
+
+def sdp_chain(q, t, params, blk_cap=None):
+    """One pair.  Returns (status, blocks ndarray[BLOCK_DT], chain_score, n_fragments)."""
+    q, t = _u8(q), _u8(t)
+    cap = int(blk_cap if blk_cap is not None else params.max_fragments)
+    out = np.zeros(max(cap, 1), dtype=BLOCK_DT)
+    n_blk, score, n_frag = C.c_uint32(0), C.c_int32(0), C.c_uint32(0)
+    st = lib().sdo_chain(q.ctypes.data_as(C.c_void_p), C.c_uint32(len(q)), t.ctypes.data_as(C.c_void_p), C.c_uint32(len(t)),
+                         C.byref(params), out.ctypes.data_as(C.c_void_p), C.c_uint32(cap),
+                         C.byref(n_blk), C.byref(score), C.byref(n_frag))
+    return st, out[:min(n_blk.value, cap)].copy(), score.value, n_frag.value
+
+
+def sdp_chain_batch(batch, params, first=0, count=None):
+    """Pairs [first, first+count) of a batch dict with spelled-out targets.  Returns
+    (status, n_blk, chain_score, n_frag, list of block arrays)."""
+    n = int(batch["n_pairs"])
+    count = n - first if count is None else count
+    caps = np.full(n, params.max_fragments, dtype=np.uint32)
+    out_off = np.arange(n, dtype=np.uint64) * np.uint64(params.max_fragments)
+    out = np.zeros(n * int(params.max_fragments), dtype=BLOCK_DT)
+    status = np.zeros(n, np.int32); n_blk = np.zeros(n, np.uint32); score = np.zeros(n, np.int32); n_frag = np.zeros(n, np.uint32)
+    arrs = {k: np.ascontiguousarray(batch[k]) for k in ("q_arena", "q_off", "t_arena", "t_off")}
+    q_len = np.ascontiguousarray(batch["q_len"], dtype=np.uint32)
+    t_len = np.ascontiguousarray(batch["t_len"], dtype=np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().sdo_chain_batch(p(arrs["q_arena"]), p(arrs["q_off"]), p(q_len), p(arrs["t_arena"]), p(arrs["t_off"]), p(t_len),
+                          C.byref(params), C.c_uint32(first), C.c_uint32(count),
+                          p(status), p(n_blk), p(score), p(n_frag), p(out), p(out_off), p(caps))
+    blks = [out[int(out_off[i]):int(out_off[i]) + int(n_blk[i])].copy() for i in range(first, first + count)]
+    s = slice(first, first + count)
+    return status[s].copy(), n_blk[s].copy(), score[s].copy(), n_frag[s].copy(), blks

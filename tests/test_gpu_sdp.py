@@ -1,0 +1,134 @@
+"""Guide production on the GPU (gba_sdp_device, through the C-ABI) against its CPU restatement
+oracle/sdp_oracle.c, bit for bit, and the guides it makes fed to the refine stage.  Parity with
+libcpp's SDPAlign is unpinned (see the oracle's header)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from blasr_amd import api as a
+    return a
+
+
+def _guides_to_host(g):
+    from blasr_amd import _lib
+    st = g["status"].cpu().numpy()
+    sc = g["chain_score"].cpu().numpy()
+    nb = g["n_blk"].cpu().numpy().view(np.uint32)
+    off = g["blk_off"].cpu().numpy().view(np.uint64)
+    blocks = np.frombuffer(g["blocks"].cpu().numpy().tobytes(), dtype=_lib.BLOCK_DT)
+    return st, sc, nb, off, blocks
+
+
+def _compare(api, oracle, ctx, batch, dbatch=None, **kw):
+    import torch
+    P = api.make_sdp_params(**kw)
+    OP = oracle.make_sdp_params(k=P.tuple_size, ins=P.ins, dele=P.dele, match=P.match, max_fragments=P.max_fragments)
+    g = ctx.sdp_device(dbatch if dbatch is not None else api.to_device(batch), P)
+    torch.cuda.synchronize()
+    assert g["rc"] == 0
+    st, sc, nb, off, blocks = _guides_to_host(g)
+    est, enb, esc, _, eb = oracle.sdp_chain_batch(batch, OP)
+    assert (st == est).all(), np.flatnonzero(st != est)[:10]
+    assert (nb == enb).all() and (sc == esc).all()
+    n = int(batch["n_pairs"])
+    assert int(g["blocks_needed"]) == int(nb.sum())
+    want_off = np.zeros(n, np.uint64); want_off[1:] = np.cumsum(nb[:-1].astype(np.uint64))
+    assert (off == want_off).all()
+    for p in range(n):
+        got = blocks[int(off[p]):int(off[p]) + int(nb[p])]
+        assert (got == eb[p]).all(), p
+    return st, g
+
+
+@pytest.mark.parametrize("tile", ["1024", "8192"])
+def test_parity_with_the_oracle(api, oracle, synth, tile, monkeypatch):
+    monkeypatch.setenv("GBA_SDP_TILE", tile)
+    ctx = api.Context(0)
+    try:
+        st, _ = _compare(api, oracle, ctx, synth.generate(48, read_len=10_000, seed=31))
+        assert (st == 0).all()
+        st, _ = _compare(api, oracle, ctx, synth.generate(300, read_len=1200, seed=32, len_jitter=900, n_frac=0.02))
+        assert (st == 0).sum() > 280
+        # decoys: unrelated windows give short chains of chance matches or nothing at all
+        st, _ = _compare(api, oracle, ctx, synth.generate(120, read_len=3000, seed=33, decoy_every=4, share_reads=True))
+        # a short tuple and a small fragment budget: many pairs are too repetitive for it
+        st, _ = _compare(api, oracle, ctx, synth.generate(80, read_len=2000, seed=34, len_jitter=1000), tuple_size=6, max_fragments=256)
+        assert (st == 8).any() and (st == 0).any()
+        st, _ = _compare(api, oracle, ctx, synth.generate(40, read_len=2500, seed=35), tuple_size=15, ins=3, dele=3, match=7, max_fragments=200)
+    finally:
+        ctx.close()
+
+
+def test_edge_cases(api, oracle):
+    import util
+    ctx = api.Context(0)
+    try:
+        rng = np.random.default_rng(5)
+        rnd = lambda n: bytes(rng.choice(list(b"ACGT"), n).tolist())
+        a = rnd(500)
+        pairs = [(b"ACGT", a, []), (a, b"ACG", []), (a, a, []), (a, a[::-1], []),
+                 (b"A" * 400, b"A" * 400, []), (b"N" * 64, b"N" * 64, []), (a[:100] + b"N" + a[100:], a, []),
+                 (a.lower(), a, []), (a[:250] + a[:250] + a[250:], a, []), (a, a[:250] + a[200:], []),
+                 (b"ACGTTGCAAGG", b"ACGTTGCAAGG", []), (rnd(3000), rnd(3000), [])]
+        batch = util.make_batch([(q, t, [(0, 0, 1)]) for q, t, _ in pairs])
+        st, _ = _compare(api, oracle, ctx, batch, max_fragments=128)
+        assert [int(s) for s in st[:3]] == [1, 1, 0] and [int(s) for s in st[4:6]] == [8, 1] and int(st[10]) == 0
+    finally:
+        ctx.close()
+
+
+def test_windows_of_a_resident_reference_on_both_strands(api, oracle, synth):
+    ctx = api.Context(0)
+    try:
+        ref = synth.reference(3_000_000, n_frac=0.01)
+        batch = synth.generate(200, read_len=2500, seed=36, ref=ref, len_jitter=1000)
+        assert 50 < int(batch["win_rc"].sum()) < 150
+        ctx.set_reference(ref)
+        st, _ = _compare(api, oracle, ctx, batch, dbatch=api.to_device(synth.as_windows(batch)))
+        assert (st == 0).sum() > 190
+    finally:
+        ctx.close()
+
+
+def test_guides_feed_the_refine_stage(api, oracle, synth):
+    """Reads -> guides on the device -> refine on the device, nothing travels in between.  The
+    refined alignments are compared with the ones the truth-derived guides of the generator give."""
+    import torch
+    from blasr_amd import _lib
+    ctx = api.Context(0)
+    try:
+        batch = synth.generate(256, read_len=8000, seed=37)
+        n = 256
+        db = api.to_device(batch)
+        ctx.set_scoring(api.make_scoring())
+        out_pairs = torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0")
+        out_blocks = torch.zeros((int(batch["q_len"].sum()) + n, 3), dtype=torch.int32, device="cuda:0")
+        rc, _ = ctx.refine_device(db, out_pairs, out_blocks)
+        assert rc == 0
+        truth = np.frombuffer(out_pairs.cpu().numpy().tobytes(), dtype=_lib.PAIR_RESULT_DT).copy()
+        g = ctx.sdp_device(db, api.make_sdp_params())
+        assert g["rc"] == 0 and int((g["status"] != 0).sum()) == 0
+        db2 = dict(db, blocks=g["blocks"], blk_off=g["blk_off"], n_blk=g["n_blk"])
+        rc, _ = ctx.refine_device(db2, out_pairs, out_blocks)
+        torch.cuda.synchronize()
+        assert rc == 0
+        mine = np.frombuffer(out_pairs.cpu().numpy().tobytes(), dtype=_lib.PAIR_RESULT_DT)
+        assert (mine["status"] == 0).all() and (truth["status"] == 0).all()
+        # the chain starts at the first and ends at the last anchor, so the refined stretch is a little
+        # shorter than with the generator's guide; per aligned base the alignments are as good
+        per_base_mine = mine["score"] / mine["rows"]
+        per_base_truth = truth["score"] / truth["rows"]
+        assert (mine["rows"] >= 0.97 * truth["rows"]).all()
+        assert np.mean(per_base_mine <= per_base_truth + 0.02) > 0.97
+        # the refined alignments agree with the oracle run on the same guides
+        st, sc, nb, off, blocks = _guides_to_host(g)
+        hb = dict(batch, blocks=blocks, blk_off=off, n_blk=nb)
+        res, _ = oracle.align_batch(hb, oracle.make_params(), first=0, count=16)
+        for f in ("score", "n_match", "n_mismatch", "n_ins", "n_del"):
+            assert (res[f] == mine[f][:16]).all(), f
+    finally:
+        ctx.close()
