@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host", action="store_true", help="skip the host-to-host measurement")
+    ap.add_argument("--no-guides", action="store_true", help="skip the guide-production measurement")
     ap.add_argument("--cigar", type=int, default=None, help="also have the device write CIGAR operations (GBA_CIGAR_* flags); not part of the default line")
     ap.add_argument("--host-steps", type=int, default=6)
     ap.add_argument("--host-contexts", type=int, default=2)
@@ -267,6 +268,40 @@ def main():
     }
     if cigar is not None:
         out["cigar"] = {"flags": args.cigar, "operations_per_step": ctx.cigar_needed}
+
+    if rank == 0 and world == 1 and not args.no_guides:
+        # The step in front of the path, on the same batch: guides made on the device from the sequences
+        # alone (k-mer matches chained, gba_sdp_device), then the refine stage run on those guides.
+        sp = api.make_sdp_params()
+        g = ctx.sdp_device(dbatch, sp, blocks_capacity=cap)             # warm-up (scratch allocation)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        g = ctx.sdp_device(dbatch, sp, blocks_capacity=cap)
+        torch.cuda.synchronize()
+        sdp_s = time.perf_counter() - t1
+        gst = g["status"].cpu().numpy()
+        d2 = dict(dbatch, blocks=g["blocks"], blk_off=g["blk_off"], n_blk=g["n_blk"])
+        ctx.refine_device(d2, out_pairs, out_blocks)
+        t1 = time.perf_counter()
+        rc2, _ = ctx.refine_device(d2, out_pairs, out_blocks)
+        torch.cuda.synchronize()
+        ref_s = time.perf_counter() - t1
+        r2 = out_pairs.cpu().numpy().view(_lib.PAIR_RESULT_DT)
+        ok2 = r2["status"] == 0
+        cells2 = int(r2["ncells"][ok2].sum())
+        both = ok2 & (res["status"] == 0)
+        out["guide_production"] = {
+            "what": "gba_sdp_device: maximal exact matches of >= %d bases chained per pair (sdpIns %d, sdpDel %d), device-resident" % (sp.tuple_size, sp.ins, sp.dele),
+            "ms_per_step": round(sdp_s * 1e3, 3), "pairs_per_sec": round(n / sdp_s, 1),
+            "pairs_with_guide": int((gst == 0).sum()), "blocks": int(g["blocks_needed"]),
+            "refine_on_these_guides": {"rc": rc2, "ms_per_step": round(ref_s * 1e3, 3), "gcups": round(cells2 / ref_s / 1e9, 2), "pairs_ok": int(ok2.sum()),
+                                       "score_per_base": round(float(r2["score"][both].sum()) / max(1, int(r2["rows"][both].sum())), 4),
+                                       "score_per_base_generator_guides": round(float(res["score"][both].sum()) / max(1, int(res["rows"][both].sum())), 4)},
+            "guides_then_refine_gcups": round(cells2 / (sdp_s + ref_s) / 1e9, 2)}
+        del g, d2
+        # what is read below is the result of the generator's guides again
+        ctx.refine_device(dbatch, out_pairs, out_blocks)
+        torch.cuda.synchronize()
 
     if rank == 0 and world == 1 and not args.no_host:
         # The same batch from host memory to host memory (gba_submit / gba_wait), measured by a child

@@ -1692,6 +1692,7 @@ struct SdpConst {
     uint32_t hit_limit;           // more k-mer hits than this in one pair: too repetitive
     uint32_t tile, slots_log2;    // target positions indexed at a time; log2 of the hash slots (= 2 * tile)
     uint32_t qwords, twords;      // dwords of a packed sequence (including two pad words)
+    uint32_t stop;                // experiments: leave the kernel after this phase (0: run it all)
 };
 
 // query codes (code + 1, 6 for letters outside ACGT) of the whole read, 32 pad bytes behind it
@@ -1731,42 +1732,32 @@ __device__ __forceinline__ uint32_t window16(const uint32_t *pk, uint32_t pos)
     return (uint32_t)(v >> b);
 }
 
-__device__ __forceinline__ bool cas16(uint32_t *tab32, uint32_t h, uint32_t expect, uint32_t val)
-{
-    uint32_t *w = tab32 + (h >> 1);
-    const uint32_t sh = (h & 1u) * 16u;
-    uint32_t old = *(volatile uint32_t *)w;
-    for (;;) {
-        if (((old >> sh) & 0xffffu) != expect) return false;
-        const uint32_t nw = (old & ~(0xffffu << sh)) | val << sh;
-        const uint32_t prev = atomicCAS(w, old, nw);
-        if (prev == old) return true;
-        old = prev;
-    }
-}
-
-__global__ __launch_bounds__(SDP_THREADS) void k_sdp(Dev d, SdpConst sc, const uint8_t *qcodes, int32_t *out_status,
-                                                       int32_t *out_score, uint32_t *out_nblk, gba_block *chains)
+// Matches of one pair: its fragments (query start << 16 | target start, length) go to frags + pair * cap in no
+// particular order, their number to nfrag (above max_fragments: too many), the pair's status to out_status.
+__global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(Dev d, SdpConst sc, const uint8_t *qcodes, int32_t *out_status,
+                                                             uint2 *frags, uint32_t *nfrag)
 {
     extern __shared__ uint32_t smem[];
-    __shared__ uint32_t s_nfrag, s_hits, s_nchain;
+    __shared__ uint32_t s_nfrag, s_hits;
     const uint32_t p = blockIdx.x, tid = threadIdx.x;
     const uint32_t SLOTS = 1u << sc.slots_log2;
-    // LDS: hash heads (u16 x SLOTS) | next (u16 x tile) | fragments (4 dwords x cap) | query bases, query marks, target bases, target marks
-    uint32_t *tab32 = smem;
-    unsigned short *nxt = (unsigned short *)(smem + SLOTS / 2);
-    uint4 *F = (uint4 *)(((uintptr_t)(smem + SLOTS / 2 + sc.tile / 2) + 15u) & ~(uintptr_t)15u);   // .x = query start << 16 | target start, .y = length, .z = score, .w = predecessor
-    uint32_t *qp = (uint32_t *)(F + sc.cap), *qs = qp + sc.qwords, *tp = qs + sc.qwords, *ts = tp + sc.twords;
+    // LDS: hash slots (SLOTS dwords: tag << 16 | head of the k-mer's list) | next (u16 x tile) | query bases, query marks,
+    // target bases, target marks.  A k-mer is spread by an odd multiplier modulo 4^k, a bijection: the slot index is the top
+    // of the product and the tag its low 16 bits, which together identify the k-mer when 2k - log2(SLOTS) <= 16; only for
+    // longer tuples is a tag match checked against the sequence.
+    uint32_t *tab = smem;
+    unsigned short *nxt = (unsigned short *)(smem + SLOTS);
+    uint32_t *qp = smem + SLOTS + sc.tile / 2, *qs = qp + sc.qwords, *tp = qs + sc.qwords, *ts = tp + sc.twords;
 
     int st = d.status[p];
     const uint32_t Q = d.Q[p], T = d.T[p];
     if (st == GBA_PAIR_OK && T > 65535u) st = GBA_PAIR_TOO_LONG;          // (the query is limited to 65 535 bases by k_meta)
     if (st == GBA_PAIR_OK && (Q < sc.k || T < sc.k)) st = GBA_PAIR_EMPTY_GUIDE;
     if (st != GBA_PAIR_OK) {                                              // uniform over the workgroup
-        if (tid == 0) { out_status[p] = st; out_score[p] = 0; out_nblk[p] = 0; }
+        if (tid == 0) { out_status[p] = st; nfrag[p] = 0; }
         return;
     }
-    if (tid == 0) { s_nfrag = 0; s_hits = 0; s_nchain = 0; }
+    if (tid == 0) { s_nfrag = 0; s_hits = 0; }
     // ---- pack both sequences: 16 bases per dword, and a dword of marks (01 per base that is no ACGT base of the sequence)
     {
         const uint8_t *qc = qcodes + align16(d.row_off[p] + 48ull * p);
@@ -1790,44 +1781,55 @@ __global__ __launch_bounds__(SDP_THREADS) void k_sdp(Dev d, SdpConst sc, const u
             (isq ? qs : ts)[ww] = marks;
         }
     }
+    if (sc.stop == 1) return;
     const uint32_t kbits = 2u * sc.k;
     const uint32_t kmark = (uint32_t)((1ull << kbits) - 1ull) & 0x55555555u;
-    const uint32_t hshift = 32u - sc.slots_log2;
-    // ---- matches, one tile of the target at a time
+    const uint32_t hshift = kbits - sc.slots_log2;                        // (the tuple has at least log2(SLOTS) bits: run_sdp sees to it)
+    const bool exact = hshift <= 16u;
+    uint2 *myfrags = frags + (uint64_t)p * sc.cap;
+    // ---- one tile of the target at a time
+    // (Measured alternatives, all slower on 10-kb reads: k-mers rolled through registers along per-thread stretches, lanes
+    // of a wave probing out of step with their hits queued for later, four independent positions per thread in flight.
+    // The kernel is bound by the instructions it issues, about 30 000 per wave and pair, not by LDS latency or conflicts.)
     for (uint32_t tile0 = 0; tile0 + sc.k <= T; tile0 += sc.tile) {
         __syncthreads();
-        for (uint32_t i = tid; i < SLOTS / 2; i += SDP_THREADS) tab32[i] = 0;
+        for (uint32_t i = tid; i < SLOTS; i += SDP_THREADS) tab[i] = 0;
         __syncthreads();
         const uint32_t tend = min(tile0 + sc.tile, T - sc.k + 1u);        // k-mers start in [tile0, tend)
         for (uint32_t y = tile0 + tid; y < tend; y += SDP_THREADS) {
             if (window16(ts, y) & kmark) continue;                        // a letter outside ACGT in the k-mer
             const uint32_t km = window16(tp, y) & sc.kmask;
-            const uint32_t yl = y - tile0, y1 = yl + 1u;
-            uint32_t h = (km * 0x9E3779B1u) >> hshift;
+            const uint32_t yl = y - tile0;
+            const uint32_t mix = (km * 0x9E3779B1u) & sc.kmask;
+            uint32_t h = mix >> hshift;
+            const uint32_t mine = mix << 16 | (yl + 1u);
             for (;;) {
-                const uint32_t v = (tab32[h >> 1] >> ((h & 1u) * 16u)) & 0xffffu;
+                const uint32_t v = *(volatile uint32_t *)&tab[h];
                 if (v == 0u) {
                     nxt[yl] = 0;
-                    if (cas16(tab32, h, 0u, y1)) break;
+                    if (atomicCAS(&tab[h], 0u, mine) == 0u) break;
                     continue;                                             // somebody took the slot: look at it again
                 }
-                if ((window16(tp, tile0 + v - 1u) & sc.kmask) == km) {    // the list of this k-mer: push in front
-                    nxt[yl] = (unsigned short)v;
-                    if (cas16(tab32, h, v, y1)) break;
+                if ((v ^ mine) >> 16 == 0u && (exact || (window16(tp, tile0 + (v & 0xffffu) - 1u) & sc.kmask) == km)) {
+                    nxt[yl] = (unsigned short)v;                          // the list of this k-mer: push in front
+                    if (atomicCAS(&tab[h], v, mine) == v) break;
                     continue;
                 }
                 h = (h + 1u) & (SLOTS - 1u);
             }
         }
         __syncthreads();
+        if (sc.stop == 5) continue;
         for (uint32_t x = tid; x + sc.k <= Q; x += SDP_THREADS) {
-            if (*(volatile uint32_t *)&s_hits > sc.hit_limit) break;
+            if ((x & (15u * SDP_THREADS)) == 0u && *(volatile uint32_t *)&s_hits > sc.hit_limit) break;     // too repetitive: give up
             if (window16(qs, x) & kmark) continue;
             const uint32_t km = window16(qp, x) & sc.kmask;
-            uint32_t h = (km * 0x9E3779B1u) >> hshift, v;
+            const uint32_t mix = (km * 0x9E3779B1u) & sc.kmask;
+            uint32_t h = mix >> hshift, v;
             for (;;) {
-                v = (tab32[h >> 1] >> ((h & 1u) * 16u)) & 0xffffu;
-                if (v == 0u || (window16(tp, tile0 + v - 1u) & sc.kmask) == km) break;
+                v = tab[h];
+                if (v == 0u) break;
+                if ((v >> 16 ^ mix) << 16 == 0u && (exact || (window16(tp, tile0 + (v & 0xffffu) - 1u) & sc.kmask) == km)) { v &= 0xffffu; break; }
                 h = (h + 1u) & (SLOTS - 1u);
             }
             uint32_t hits = 0;
@@ -1848,90 +1850,112 @@ __global__ __launch_bounds__(SDP_THREADS) void k_sdp(Dev d, SdpConst sc, const u
                     len += 16u;
                 }
                 const uint32_t at = atomicAdd(&s_nfrag, 1u);
-                if (at < sc.cap) F[at] = make_uint4(x << 16 | y, len, 0u, 0xffffu);
+                if (at < sc.cap) myfrags[at] = make_uint2(x << 16 | y, len);
             }
             if (hits) atomicAdd(&s_hits, hits);
         }
     }
     __syncthreads();
-    const uint32_t n = s_nfrag;
-    if (n > sc.max_fragments || s_hits > sc.hit_limit || n == 0u) {
-        if (tid == 0) { out_status[p] = n == 0u && s_hits <= sc.hit_limit ? GBA_PAIR_EMPTY_GUIDE : GBA_PAIR_TOO_MANY; out_score[p] = 0; out_nblk[p] = 0; }
+    if (tid == 0) {
+        const uint32_t n = s_nfrag;
+        const bool many = n > sc.max_fragments || s_hits > sc.hit_limit;
+        out_status[p] = many ? GBA_PAIR_TOO_MANY : n == 0u ? GBA_PAIR_EMPTY_GUIDE : GBA_PAIR_OK;
+        nfrag[p] = many ? 0u : n;
+    }
+}
+
+// Chain of one pair: one wave.  Sorts the pair's fragments in LDS, settles them 64 at a time, traces the best chain
+// back and writes its blocks to chains + pair * max_fragments.
+__global__ __launch_bounds__(64) void k_sdp_chain(SdpConst sc, const uint2 *frags, const uint32_t *nfrag, int32_t *out_score,
+                                                   uint32_t *out_nblk, gba_block *chains)
+{
+    extern __shared__ uint32_t smem[];
+    uint4 *F = (uint4 *)(((uintptr_t)smem + 15u) & ~(uintptr_t)15u);      // .x = query start << 16 | target start, .y = length, .z = score, .w = predecessor
+    const uint32_t p = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = nfrag[p];
+    if (n == 0u) {
+        if (tid == 0) { out_score[p] = 0; out_nblk[p] = 0; }
         return;
     }
-    // ---- sort by (query start, target start)
     uint32_t P2 = 1;
     while (P2 < n) P2 <<= 1;
-    for (uint32_t i = n + tid; i < P2; i += SDP_THREADS) F[i] = make_uint4(0xffffffffu, 0u, 0u, 0xffffu);
+    {
+        const uint2 *src = frags + (uint64_t)p * sc.cap;
+        for (uint32_t i = tid; i < P2; i += 64) {
+            const uint2 f = i < n ? src[i] : make_uint2(0xffffffffu, 0u);
+            F[i] = make_uint4(f.x, f.y, 0u, 0xffffu);
+        }
+    }
     __syncthreads();
+    if (sc.stop == 2) return;
+    // ---- sort by (query start, target start): bitonic, one compare-exchange per lane and step
     for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1)
         for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < P2; i += SDP_THREADS) {
-                const uint32_t o = i ^ j;
-                if (o > i) {
-                    const uint4 a = F[i], b = F[o];
-                    if ((a.x > b.x) == ((i & k2) == 0u)) { F[i] = b; F[o] = a; }
-                }
+            for (uint32_t e = tid; e < P2 / 2; e += 64) {
+                const uint32_t i = ((e & ~(j - 1u)) << 1) | (e & (j - 1u)), o = i | j;       // the pair (i, i + j) number e
+                const uint4 a = F[i], b = F[o];
+                if ((a.x > b.x) == ((i & k2) == 0u)) { F[i] = b; F[o] = a; }
             }
             __syncthreads();
         }
-    // ---- chain (one wave)
-    if (tid < 64u) {
-        const int32_t M = sc.match, INS = sc.ins, DEL = sc.del;
-        int32_t best_all = 0; uint32_t end = 0;
-        for (uint32_t b0 = 0; b0 < n; b0 += 64) {
-            const uint32_t f = b0 + tid;
-            const bool live = f < n;
-            const uint4 me = live ? F[f] : make_uint4(0u, 0u, 0u, 0u);
-            const int32_t x = (int32_t)(me.x >> 16), y = (int32_t)(me.x & 0xffffu), diag = y - x;
-            int32_t best = 0; uint32_t bp = 0xffffu;
-            auto relax = [&](uint4 pr, uint32_t pidx, bool allowed) {
-                const int32_t px = (int32_t)(pr.x >> 16), py = (int32_t)(pr.x & 0xffffu), pl = (int32_t)pr.y;
-                const int32_t o = max(max(px + pl - x, py + pl - y), 0);
-                const int32_t dd = diag - (py - px);
-                const int32_t g = (int32_t)pr.z - max(dd * DEL, -dd * INS) - o * M;
-                if (allowed && o < pl && g > best) { best = g; bp = pidx; }
-            };
-            for (uint32_t q0 = 0; q0 < b0; q0++) relax(F[q0], q0, true);
-            // the fragments of this round among themselves: lane j is final once lanes 0..j-1 have been offered to it
-            const uint32_t lim = min(64u, n - b0);
-            for (uint32_t j = 0; j < lim; j++) {
-                const int32_t mine = (int32_t)me.y * M + best;
-                uint4 pr;
-                pr.x = (uint32_t)__builtin_amdgcn_readlane((int32_t)me.x, j);
-                pr.y = (uint32_t)__builtin_amdgcn_readlane((int32_t)me.y, j);
-                pr.z = (uint32_t)__builtin_amdgcn_readlane(mine, j);
-                relax(pr, b0 + j, tid > j);
-            }
-            if (live) {
-                const int32_t sc_f = (int32_t)me.y * M + best;
-                F[f].z = (uint32_t)sc_f; F[f].w = bp;
-            }
-            // best end so far: the highest score, the earliest fragment on ties
-            int32_t v = live ? (int32_t)me.y * M + best : 0;
-            uint32_t vi = f;
+    if (sc.stop == 3) return;
+    // ---- chain
+    const int32_t M = sc.match, INS = sc.ins, DEL = sc.del;
+    int32_t best_all = 0; uint32_t end = 0;
+    for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+        const uint32_t f = b0 + tid;
+        const bool live = f < n;
+        const uint4 me = live ? F[f] : make_uint4(0u, 0u, 0u, 0u);
+        const int32_t x = (int32_t)(me.x >> 16), y = (int32_t)(me.x & 0xffffu), diag = y - x;
+        int32_t best = 0; uint32_t bp = 0xffffu;
+        auto relax = [&](uint4 pr, uint32_t pidx, bool allowed) {
+            const int32_t px = (int32_t)(pr.x >> 16), py = (int32_t)(pr.x & 0xffffu), pl = (int32_t)pr.y;
+            const int32_t o = max(max(px + pl - x, py + pl - y), 0);
+            const int32_t dd = diag - (py - px);
+            const int32_t g = (int32_t)pr.z - max(dd * DEL, -dd * INS) - o * M;
+            if (allowed && o < pl && g > best) { best = g; bp = pidx; }
+        };
+        for (uint32_t q0 = 0; q0 < b0; q0++) relax(F[q0], q0, true);
+        // the fragments of this round among themselves: lane j is final once lanes 0..j-1 have been offered to it
+        const uint32_t lim = min(64u, n - b0);
+        for (uint32_t j = 0; j < lim; j++) {
+            const int32_t mine = (int32_t)me.y * M + best;
+            uint4 pr;
+            pr.x = (uint32_t)__builtin_amdgcn_readlane((int32_t)me.x, j);
+            pr.y = (uint32_t)__builtin_amdgcn_readlane((int32_t)me.y, j);
+            pr.z = (uint32_t)__builtin_amdgcn_readlane(mine, j);
+            pr.w = 0;
+            relax(pr, b0 + j, tid > j);
+        }
+        if (live) {
+            const int32_t sc_f = (int32_t)me.y * M + best;
+            F[f].z = (uint32_t)sc_f; F[f].w = bp;
+        }
+        // best end so far: the highest score, the earliest fragment on ties
+        int32_t v = live ? (int32_t)me.y * M + best : 0;
+        uint32_t vi = f;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int32_t ov = __shfl_xor(v, o, 64);
-                const uint32_t oi = (uint32_t)__shfl_xor((int)vi, o, 64);
-                if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
-            }
-            if (v > best_all) { best_all = v; end = vi; }
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t ov = __shfl_xor(v, o, 64);
+            const uint32_t oi = (uint32_t)__shfl_xor((int)vi, o, 64);
+            if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
         }
-        // trace back (one lane), the chain's fragment numbers go where the scores were, last first
-        if (tid == 0) {
-            uint32_t cnt = 0;
-            for (uint32_t f = end; f != 0xffffu; f = F[f].w) cnt++;
-            uint32_t i = cnt;
-            for (uint32_t f = end; f != 0xffffu;) { const uint32_t nf = F[f].w; F[--i].z = f; f = nf; }
-            s_nchain = cnt;
-            out_status[p] = GBA_PAIR_OK; out_score[p] = best_all; out_nblk[p] = cnt;
-        }
+        if (v > best_all) { best_all = v; end = vi; }
+        __syncthreads();
     }
+    if (sc.stop == 4) return;
+    // trace back: lane 0 counts the chain and writes its fragment numbers where the scores were, last first
+    uint32_t nc = 0;
+    if (tid == 0) {
+        for (uint32_t f = end; f != 0xffffu; f = F[f].w) nc++;
+        uint32_t i = nc;
+        for (uint32_t f = end; f != 0xffffu;) { const uint32_t nf = F[f].w; F[--i].z = f; f = nf; }
+        out_score[p] = best_all; out_nblk[p] = nc;
+    }
+    nc = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)nc);
     __syncthreads();
-    const uint32_t nc = s_nchain;
     gba_block *outb = chains + (uint64_t)p * sc.max_fragments;
-    for (uint32_t i = tid; i < nc; i += SDP_THREADS) {
+    for (uint32_t i = tid; i < nc; i += 64) {
         const uint4 a = F[F[i].z];
         uint32_t len = a.y;
         if (i + 1 < nc) {
@@ -2016,7 +2040,12 @@ struct gba_ctx {
     bool have_scoring = false;
     bool lds_attr_set = false;       // the fill kernels' dynamic-LDS limit has been raised on this device
     bool sdp_attr_set = false;       // the same for k_sdp
-    uint32_t sdp_tile_max = 8192;    // target positions indexed at a time by k_sdp, at most (env GBA_SDP_TILE; power of two, 1024..16384)
+    // k_sdp_match: target positions indexed at a time, at most (env GBA_SDP_TILE; power of two, 1024..16384), and hash slots
+    // per indexed position (env GBA_SDP_SLOTS: 2 or 4).  Measured on 32 768 pairs of 10 kb, whole guide production:
+    // 2048 x 4: 13.7 ms; 1024 x 4: 14.2; 4096 x 2: 15.1; 2048 x 2: 15.3; 4096 x 4: 22.9; 8192 x 2: 25.5 (LDS for one
+    // workgroup per CU only)
+    uint32_t sdp_tile_max = 2048;
+    uint32_t sdp_slots_per_pos = 4;
     gba_scoring sc;
     FillConst fc;
     TbConst tbc;
@@ -2548,8 +2577,11 @@ int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides
     k.max_fragments = sp->max_fragments;
     k.cap = 64; while (k.cap < k.max_fragments) k.cap <<= 1;
     k.hit_limit = 64u * k.max_fragments;
+    k.stop = 0;
+    if (const char *e = getenv("GBA_SDP_STOP")) k.stop = (uint32_t)atoi(e);
     if (!c->sdp_attr_set) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_sdp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));   // the kernel has a few static words too
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_sdp_match, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));   // the kernel has a few static words too
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_sdp_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         c->sdp_attr_set = true;
     }
     for (uint32_t first = 0; first < n; first += per) {
@@ -2591,12 +2623,22 @@ int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides
         hipLaunchKernelGGL(k_pack_q, dim3(cnt), dim3(256), 0, s, d, qcodes);
         // the target is indexed a tile at a time: a tile of half the hash slots, sized to the longest window (up to SDP_TILE_MAX)
         k.tile = 1024; while (k.tile < maxT && k.tile < c->sdp_tile_max) k.tile <<= 1;
-        k.slots_log2 = 1; while ((1u << k.slots_log2) < 2 * k.tile) k.slots_log2++;
+        k.slots_log2 = 1; while ((1u << k.slots_log2) < c->sdp_slots_per_pos * k.tile) k.slots_log2++;
+        while (k.slots_log2 > 2u * k.k) k.slots_log2--;                 // short tuples: no more slots than k-mers exist
         k.qwords = maxQ / 16 + 3; k.twords = maxT / 16 + 3;
-        const size_t lds = ((size_t)(1u << k.slots_log2) / 2 + k.tile / 2 + (size_t)k.cap * 4 + 2 * (size_t)(k.qwords + k.twords)) * 4 + 16;
+        size_t lds;
+        for (;;) {
+            lds = ((size_t)(1u << k.slots_log2) + k.tile / 2 + 2 * (size_t)(k.qwords + k.twords)) * 4;
+            if (lds <= 160 * 1024 - 256 || k.tile <= 1024) break;
+            k.tile >>= 1; k.slots_log2--;                                   // long sequences leave less room for the table
+        }
         if (lds > 160 * 1024 - 256) return GBA_E_UNSUPPORTED;
-        hipLaunchKernelGGL(k_sdp, dim3(cnt), dim3(SDP_THREADS), lds, s, d, k, (const uint8_t *)qcodes, out->status + first, out->chain_score + first,
-                           out->n_blk + first, (gba_block *)sl.b_blk.ptr);
+        { int rc = ensure(c, sl.b_guide, (size_t)cnt * k.cap * sizeof(uint2) + 16); if (rc) return rc; }
+        uint32_t *nfrag = d.span;                  // a spare per-pair array
+        hipLaunchKernelGGL(k_sdp_match, dim3(cnt), dim3(SDP_THREADS), lds, s, d, k, (const uint8_t *)qcodes, out->status + first,
+                           (uint2 *)sl.b_guide.ptr, nfrag);
+        hipLaunchKernelGGL(k_sdp_chain, dim3(cnt), dim3(64), (size_t)k.cap * 16 + 16, s, k, (const uint2 *)sl.b_guide.ptr, (const uint32_t *)nfrag,
+                           out->chain_score + first, out->n_blk + first, (gba_block *)sl.b_blk.ptr);
         hipLaunchKernelGGL(k_scan_cnt, dim3(1), dim3(SCAN_T), 0, s, (const uint32_t *)(out->n_blk + first), out->blk_off + first, cnt, needed);
         hipLaunchKernelGGL(k_sdp_emit, dim3(cnt), dim3(256), 0, s, (const gba_block *)sl.b_blk.ptr, k.max_fragments,
                            (const uint32_t *)(out->n_blk + first), (const uint64_t *)(out->blk_off + first), out->blocks, out->blocks_capacity, out->status + first);
@@ -2666,6 +2708,7 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
             const uint32_t v = (uint32_t)strtoul(e, nullptr, 10);
             if (v >= 1024 && v <= 16384 && (v & (v - 1)) == 0) c->sdp_tile_max = v;
         }
+        if (const char *e = getenv("GBA_SDP_SLOTS")) { const int v = atoi(e); if (v == 2 || v == 4) c->sdp_slots_per_pos = (uint32_t)v; }
         for (int h = 0; h < NSLOT && !rc; h++) {
             Slot &sl = c->slot[h];
             if (h == 0) sl.s = c->stream;
