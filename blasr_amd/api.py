@@ -194,7 +194,29 @@ class Context:
         rc, needed = self.wait_host()
         return pairs, blocks[:min(needed, int(blocks_capacity))], ops[:min(self.cigar_needed, len(ops))], off, rc
 
-    # ---- guide production (device-resident tensors)
+    # ---- guide production
+    def sdp_host(self, batch, params, blocks_capacity=None):
+        """gba_sdp on a host batch (numpy arrays; its guide entries are not read).  Returns
+        (status int32[n], chain_score int32[n], n_blk uint32[n], blk_off uint64[n], blocks
+        ndarray[BLOCK_DT], rc)."""
+        n = int(batch["n_pairs"])
+        if blocks_capacity is None:
+            blocks_capacity = max(1, int(np.asarray(batch["q_len"]).astype(np.uint64).sum()) // 8 + n)
+        keep = {k: np.ascontiguousarray(batch[k], dtype=dt) for k, dt in
+                (("q_arena", np.uint8), ("q_off", np.uint64), ("q_len", np.uint32), ("t_off", np.uint64), ("t_len", np.uint32))}
+        for k in ("t_arena", "t_rc"):
+            if batch.get(k) is not None:
+                keep[k] = np.ascontiguousarray(batch[k], dtype=np.uint8)
+        ta, trc = keep.get("t_arena"), keep.get("t_rc")
+        b = Batch(n, _ptr(keep["q_arena"]), _ptr(keep["q_off"]), _ptr(keep["q_len"]), _ptr(ta) if ta is not None else None,
+                  _ptr(keep["t_off"]), _ptr(keep["t_len"]), None, None, None, keep["q_arena"].size, ta.size if ta is not None else 0, 0,
+                  _ptr(trc) if trc is not None else None)
+        status = np.zeros(n, np.int32); score = np.zeros(n, np.int32); n_blk = np.zeros(n, np.uint32); off = np.zeros(n, np.uint64)
+        blocks = np.zeros(int(blocks_capacity), dtype=BLOCK_DT)
+        r = Guides(_ptr(status), _ptr(score), _ptr(n_blk), _ptr(off), _ptr(blocks), int(blocks_capacity), 0)
+        rc = self._check(self._L.gba_sdp(self._h, C.byref(b), C.byref(params), C.byref(r)), allow=(_lib.E_NOSPACE,))
+        return status, score, n_blk, off, blocks[:min(int(r.blocks_needed), int(blocks_capacity))], rc
+
     def sdp_device(self, dbatch, params, blocks_capacity=None):
         """gba_sdp_device on a device batch (as for refine_device; its "blocks", "blk_off", "n_blk"
         are not read).  Returns a dict of torch tensors on the batch's device: status (int32),

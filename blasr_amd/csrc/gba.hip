@@ -2558,6 +2558,8 @@ constexpr uint32_t SDP_PART = 32768;
 
 int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides *out)
 {
+    if (sp->tuple_size < 4 || sp->tuple_size > 15 || sp->match < 1 || sp->match > 127 || sp->ins < 0 || sp->ins > 127 ||
+        sp->del < 0 || sp->del > 127 || sp->max_fragments < 1 || sp->max_fragments > 4096) return GBA_E_UNSUPPORTED;
     const uint32_t n = b->n_pairs;
     out->blocks_needed = 0;
     if (n == 0) return GBA_OK;
@@ -3028,12 +3030,59 @@ int gba_sdp_device(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba
 {
     if (!c || !b || !sp || !out) return GBA_E_INVALID;
     if (c->in_flight) return GBA_E_STATE;
-    if (sp->tuple_size < 4 || sp->tuple_size > 15 || sp->match < 1 || sp->match > 127 || sp->ins < 0 || sp->ins > 127 ||
-        sp->del < 0 || sp->del > 127 || sp->max_fragments < 1 || sp->max_fragments > 4096) return GBA_E_UNSUPPORTED;
     if (b->n_pairs && (!b->q_arena || !b->q_off || !b->t_off || !b->q_len || !b->t_len)) return GBA_E_INVALID;
     if (b->n_pairs && (!out->status || !out->chain_score || !out->n_blk || !out->blk_off || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
     if (b->n_pairs && !b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
     return run_sdp(c, b, sp, out);
+}
+
+// The same from and to host buffers: the sequences travel in, the guides travel out (synchronous).
+int gba_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides *out)
+{
+    if (!c || !b || !sp || !out) return GBA_E_INVALID;
+    if (c->in_flight) return GBA_E_STATE;
+    const uint32_t n = b->n_pairs;
+    out->blocks_needed = 0;
+    if (n == 0) return GBA_OK;
+    if (!b->q_arena || !b->q_off || !b->t_off || !b->q_len || !b->t_len) return GBA_E_INVALID;
+    if (!out->status || !out->chain_score || !out->n_blk || !out->blk_off || (!out->blocks && out->blocks_capacity)) return GBA_E_INVALID;
+    if (!b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    struct { Buf *buf; const void *src; size_t bytes; } in[] = {
+        {&c->s_q, b->q_arena, (size_t)b->q_arena_bytes}, {&c->s_t, b->t_arena, b->t_arena ? (size_t)b->t_arena_bytes : 0},
+        {&c->s_qoff, b->q_off, (size_t)n * 8}, {&c->s_toff, b->t_off, (size_t)n * 8},
+        {&c->s_qlen, b->q_len, (size_t)n * 4}, {&c->s_tlen, b->t_len, (size_t)n * 4}, {&c->s_trc, b->t_rc, b->t_rc ? (size_t)n : 0}};
+    hipStream_t s = c->slot[0].s;
+    for (auto &x : in) {
+        if ((rc = ensure(c, *x.buf, x.bytes + 16))) return rc;
+        if (x.bytes) HIPCHK(c, hipMemcpyAsync(x.buf->ptr, x.src, x.bytes, hipMemcpyHostToDevice, s));
+    }
+    // device copies of the outputs: status | score | n_blk (4 bytes each) in s_res, offsets in s_boff, blocks in s_blk
+    if ((rc = ensure(c, c->s_res, (size_t)n * 12 + 16))) return rc;
+    if ((rc = ensure(c, c->s_boff, (size_t)n * 8 + 16))) return rc;
+    if ((rc = ensure(c, c->s_blk, (size_t)out->blocks_capacity * sizeof(gba_block) + 16))) return rc;
+    gba_batch db = *b;
+    db.q_arena = (const uint8_t *)c->s_q.ptr; db.t_arena = b->t_arena ? (const uint8_t *)c->s_t.ptr : nullptr;
+    db.t_rc = b->t_rc ? (const uint8_t *)c->s_trc.ptr : nullptr;
+    db.q_off = (const uint64_t *)c->s_qoff.ptr; db.t_off = (const uint64_t *)c->s_toff.ptr;
+    db.q_len = (const uint32_t *)c->s_qlen.ptr; db.t_len = (const uint32_t *)c->s_tlen.ptr;
+    db.blocks = nullptr; db.blk_off = nullptr; db.n_blk = nullptr;
+    gba_guides dg;
+    dg.status = (int32_t *)c->s_res.ptr; dg.chain_score = dg.status + n; dg.n_blk = (uint32_t *)(dg.status + 2 * (size_t)n);
+    dg.blk_off = (uint64_t *)c->s_boff.ptr; dg.blocks = (gba_block *)c->s_blk.ptr;
+    dg.blocks_capacity = out->blocks_capacity; dg.blocks_needed = 0;
+    rc = run_sdp(c, &db, sp, &dg);
+    if (rc != GBA_OK && rc != GBA_E_NOSPACE) return rc;
+    out->blocks_needed = dg.blocks_needed;
+    HIPCHK(c, hipMemcpyAsync(out->status, dg.status, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(out->chain_score, dg.chain_score, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(out->n_blk, dg.n_blk, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(out->blk_off, dg.blk_off, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    const uint64_t nb = dg.blocks_needed < out->blocks_capacity ? dg.blocks_needed : out->blocks_capacity;
+    if (nb) HIPCHK(c, hipMemcpyAsync(out->blocks, dg.blocks, (size_t)nb * sizeof(gba_block), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return rc;
 }
 
 int gba_set_reference(gba_ctx *c, const uint8_t *ref, uint64_t len)

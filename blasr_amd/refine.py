@@ -12,7 +12,7 @@ from typing import List, Optional
 import numpy as np
 
 from . import _lib
-from .api import make_scoring
+from .api import make_scoring, make_sdp_params
 
 BLOCK_DT = _lib.BLOCK_DT
 
@@ -38,6 +38,10 @@ class MappingParameters:
     maxScore: int = -200
     maxBandSize: int = 250   # libcpp's MAX_BAND_SIZE (ctest/concordant.t:23 mentions it)
     tieBreak: int = _lib.TIE_DIAG_LEFT_UP
+    sdpTupleSize: int = 11   # :222
+    sdpIns: int = 5          # :220
+    sdpDel: int = 10         # :221
+    sdpMaxFragments: int = 1024   # not a BLASR option: the device's budget of maximal matches per candidate
     scoreMatrix: Optional[list] = None     # 5x5, -scoreMatrix (Blasr.cpp:922-937)
 
 
@@ -159,6 +163,39 @@ def copy_back(read: bytes, cands: List[AlignmentCandidate], batch, pairs, blocks
         c.qAlignedSeqPos += c.qPos
         c.tPos, c.qPos = int(r["t_pos"]), int(r["q_pos"])
         c.tAlignedSeqLength, c.qAlignedSeqLength = tl, ql
+
+
+def SDPAlignCandidates(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx):
+    """The guide of every candidate of a read in one call: what AlignIntervals does per candidate with
+    SDPAlign(alignment->qAlignedSeq, alignment->tAlignedSeq, distScoreFn, sdpTupleSize, params.sdpIns,
+    params.sdpDel, params.indelRate*3, *alignment, mappingBuffers, Local, ...)
+    (/root/reference/iblasr/BlasrAlignImpl.hpp:980-987).  The query is the read from qAlignedSeqPos
+    on (qAlignedSeqLength bases, the rest of the read when that is 0), the target the candidate's
+    window.  On return blocks are relative to the first block and qPos / tPos give its start, the
+    convention of :951-964; a candidate without a single match of sdpTupleSize bases keeps no blocks."""
+    n = len(cands)
+    if n == 0:
+        return cands
+    q_arena = np.frombuffer(read, dtype=np.uint8)
+    q_off = np.array([c.qAlignedSeqPos for c in cands], np.uint64)
+    q_len = np.array([c.qAlignedSeqLength or len(read) - c.qAlignedSeqPos for c in cands], np.uint32)
+    t_len = np.array([len(c.tAlignedSeq) for c in cands], np.uint32)
+    t_off = np.zeros(n, np.uint64); t_off[1:] = np.cumsum(t_len[:-1].astype(np.uint64))
+    t_arena = np.frombuffer(b"".join(c.tAlignedSeq for c in cands) or b"N", dtype=np.uint8)
+    batch = {"n_pairs": n, "q_arena": q_arena, "q_off": q_off, "q_len": q_len, "t_arena": t_arena, "t_off": t_off, "t_len": t_len}
+    sp = make_sdp_params(tuple_size=params.sdpTupleSize, ins=params.sdpIns, dele=params.sdpDel, match=-params.match,
+                         max_fragments=params.sdpMaxFragments)
+    status, score, n_blk, off, blocks, rc = ctx.sdp_host(batch, sp, blocks_capacity=n * params.sdpMaxFragments)
+    for i, c in enumerate(cands):
+        c.status = int(status[i])
+        b = blocks[int(off[i]):int(off[i]) + int(n_blk[i])].copy() if c.status == _lib.PAIR_OK else np.zeros(0, dtype=BLOCK_DT)
+        c.qPos = c.tPos = 0
+        if len(b):
+            c.qPos, c.tPos = int(b[0]["q_pos"]), int(b[0]["t_pos"])
+            b["q_pos"] -= np.uint32(c.qPos); b["t_pos"] -= np.uint32(c.tPos)
+        c.blocks = b
+        c.score = -int(score[i])              # lower is better, like every score of the reference
+    return cands
 
 
 def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx):

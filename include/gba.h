@@ -277,6 +277,10 @@ typedef struct {
  * blocks_capacity (pairs that did not fit have GBA_PAIR_NOSPACE). */
 int gba_sdp_device(gba_ctx *ctx, const gba_batch *device_batch, const gba_sdp_params *params, gba_guides *device_out);
 
+/* The same for host buffers (every pointer of the batch and of the guides is a host pointer): copies the
+ * sequences in, returns when the guides have been copied out. */
+int gba_sdp(gba_ctx *ctx, const gba_batch *host_batch, const gba_sdp_params *params, gba_guides *host_out);
+
 /* Keeps a copy of the reference (genome, ASCII; `ref` is a host pointer) in device
  * memory for batches whose t_arena is NULL; len == 0 drops it.  Replaces the
  * per-candidate window copies out of the genome, iblasr/BlasrAlignImpl.hpp:727-743. */

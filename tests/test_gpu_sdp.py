@@ -132,3 +132,43 @@ def test_guides_feed_the_refine_stage(api, oracle, synth):
             assert (res[f] == mine[f][:16]).all(), f
     finally:
         ctx.close()
+
+
+def test_host_mirror_guides_then_refine(api, oracle, synth):
+    """The read-level mirror: SDPAlignCandidates fills the candidates' guides, RefineAlignments refines
+    them; both against the oracle's two stages run one after the other on the same sequences."""
+    from blasr_amd import refine
+    batch = synth.generate(6, read_len=2500, seed=41)
+    ctx = api.Context(0)
+    try:
+        params = refine.MappingParameters()
+        read = bytes(synth.pair(batch, 0)[0])
+        # the read's own window, a window of another read (chance matches at best), and its own window cut short
+        windows = [bytes(synth.pair(batch, 0)[1]), bytes(synth.pair(batch, 1)[1]), bytes(synth.pair(batch, 0)[1])[300:1800]]
+        cands = [refine.AlignmentCandidate(tAlignedSeq=w) for w in windows]
+        refine.SDPAlignCandidates(read, cands, params, ctx)
+        op = oracle.make_params()
+        expect = []
+        for c, w in zip(cands, windows):
+            st, blks, score, _ = oracle.sdp_chain(read, w, oracle.make_sdp_params(max_fragments=1024))
+            assert c.status == st
+            if st != 0:
+                assert len(c.blocks) == 0
+                continue
+            assert c.score == -score and (c.qPos, c.tPos) == (int(blks[0]["q_pos"]), int(blks[0]["t_pos"]))
+            assert (c.blocks["q_pos"] + c.qPos == blks["q_pos"]).all() and (c.blocks["t_pos"] + c.tPos == blks["t_pos"]).all()
+            assert (c.blocks["length"] == blks["length"]).all()
+            # what the refine stage must make of this guide: the oracle on the slices RefineAlignment cuts (:693-703)
+            last = c.blocks[-1]
+            ql, tl = int(last["q_pos"]) + int(last["length"]), int(last["t_pos"]) + int(last["length"])
+            res, rb = oracle.align(read[c.qPos:c.qPos + ql], w[c.tPos:c.tPos + tl], c.blocks, op)
+            expect.append((w, res, rb))
+        kept = [c for c in cands if c.status == 0]
+        refine.RefineAlignments(read, kept, params, ctx)
+        assert kept[0].nMatch > 1500 and kept[0].score <= kept[-1].score         # sorted by score, the true locus first
+        for w, res, rb in expect:
+            c = next(k for k in kept if k.score == res["score"] and k.nMatch == res["n_match"])
+            assert (c.nMismatch, c.nIns, c.nDel) == (res["n_mismatch"], res["n_ins"], res["n_del"])
+            assert len(c.blocks) == len(rb) and (c.blocks["length"] == rb["length"]).all()
+    finally:
+        ctx.close()
