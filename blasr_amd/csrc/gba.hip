@@ -1742,9 +1742,9 @@ __global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(Dev d, SdpConst sc, c
     const uint32_t p = blockIdx.x, tid = threadIdx.x;
     const uint32_t SLOTS = 1u << sc.slots_log2;
     // LDS: hash slots (SLOTS dwords: tag << 16 | head of the k-mer's list) | next (u16 x tile) | query bases, query marks,
-    // target bases, target marks.  A k-mer is spread by an odd multiplier modulo 4^k, a bijection: the slot index is the top
-    // of the product and the tag its low 16 bits, which together identify the k-mer when 2k - log2(SLOTS) <= 16; only for
-    // longer tuples is a tag match checked against the sequence.
+    // target bases, target marks.  A k-mer is spread by an odd multiplier modulo 4^k; the slot index is the top of the
+    // product, the tag its low 16 bits.  A tag match is always checked against the sequence: an entry that linear probing
+    // has moved off its home slot is no longer identified by slot and tag.
     uint32_t *tab = smem;
     unsigned short *nxt = (unsigned short *)(smem + SLOTS);
     uint32_t *qp = smem + SLOTS + sc.tile / 2, *qs = qp + sc.qwords, *tp = qs + sc.qwords, *ts = tp + sc.twords;
@@ -1785,7 +1785,6 @@ __global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(Dev d, SdpConst sc, c
     const uint32_t kbits = 2u * sc.k;
     const uint32_t kmark = (uint32_t)((1ull << kbits) - 1ull) & 0x55555555u;
     const uint32_t hshift = kbits - sc.slots_log2;                        // (the tuple has at least log2(SLOTS) bits: run_sdp sees to it)
-    const bool exact = hshift <= 16u;
     uint2 *myfrags = frags + (uint64_t)p * sc.cap;
     // ---- one tile of the target at a time
     // (Measured alternatives, all slower on 10-kb reads: k-mers rolled through registers along per-thread stretches, lanes
@@ -1810,7 +1809,7 @@ __global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(Dev d, SdpConst sc, c
                     if (atomicCAS(&tab[h], 0u, mine) == 0u) break;
                     continue;                                             // somebody took the slot: look at it again
                 }
-                if ((v ^ mine) >> 16 == 0u && (exact || (window16(tp, tile0 + (v & 0xffffu) - 1u) & sc.kmask) == km)) {
+                if ((v ^ mine) >> 16 == 0u && (window16(tp, tile0 + (v & 0xffffu) - 1u) & sc.kmask) == km) {
                     nxt[yl] = (unsigned short)v;                          // the list of this k-mer: push in front
                     if (atomicCAS(&tab[h], v, mine) == v) break;
                     continue;
@@ -1829,7 +1828,7 @@ __global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(Dev d, SdpConst sc, c
             for (;;) {
                 v = tab[h];
                 if (v == 0u) break;
-                if ((v >> 16 ^ mix) << 16 == 0u && (exact || (window16(tp, tile0 + (v & 0xffffu) - 1u) & sc.kmask) == km)) { v &= 0xffffu; break; }
+                if ((v >> 16 ^ mix) << 16 == 0u && (window16(tp, tile0 + (v & 0xffffu) - 1u) & sc.kmask) == km) { v &= 0xffffu; break; }
                 h = (h + 1u) & (SLOTS - 1u);
             }
             uint32_t hits = 0;

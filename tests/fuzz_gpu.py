@@ -4,6 +4,10 @@
 Draws random workloads (synthetic reads with random error rates and guide sparsity, and
 adversarial pairs whose guides are random increasing blocks over random sequences) and random
 scoring / band / mode parameters, runs both sides and compares every result field and every block.
+Every second round also asks the device for the CIGAR operations (random flags) and compares a
+sample of pairs with blasr_amd.emit.cigar_ops on the returned blocks; every third round runs the
+guide producer (gba_sdp, random tuple size / penalties / fragment budget) on the round's sequences
+against oracle/sdp_oracle.c.
 Mismatches are written to gpurun_out/fuzz_fail_<k>.json with everything needed to replay them.
 
 usage: python tests/fuzz_gpu.py [--seconds 120] [--seed 1]
@@ -81,19 +85,73 @@ def random_adversarial(rng, util):
     return util.make_batch(pairs)
 
 
+_LETTER = np.full(256, ord("N"), np.uint8)
+for _c in b"ACGT":
+    _LETTER[_c] = _c
+    _LETTER[_c + 32] = _c
+
+
+def check_cigars(rng, emit, _lib, batch, pairs, blocks, ops, off, flags):
+    """A sample of the round's pairs: device operations == host restatement on the same blocks."""
+    n = int(batch["n_pairs"])
+    if int(off[n]) != len(ops):
+        return (n, "cigar_total", int(off[n]), len(ops))
+    for p in rng.choice(n, size=min(n, 12), replace=False):
+        p = int(p)
+        k = pairs[p]
+        got = [(int(w) >> 4, _lib.CIGAR_OPS[int(w) & 15]) for w in ops[int(off[p]):int(off[p + 1])]]
+        if int(k["status"]) != 0:
+            if got:
+                return (p, "cigar_of_failed_pair", 0, len(got))
+            continue
+        qo, ql = int(batch["q_off"][p]), int(batch["q_len"][p])
+        to, tl = int(batch["t_off"][p]), int(batch["t_len"][p])
+        q = _LETTER[batch["q_arena"][qo:qo + ql]].tobytes()
+        t = _LETTER[batch["t_arena"][to:to + tl]].tobytes()
+        kb = blocks[int(k["blk_off"]):int(k["blk_off"]) + int(k["n_blk"])]
+        want = emit.cigar_ops(kb, q, t, int(k["q_pos"]), int(k["t_pos"]), use_seq_match=bool(flags & 1), allow_adjacent_indels=bool(flags & 2))
+        if got != want:
+            return (p, "cigar", len(want), len(got))
+    return None
+
+
+def check_sdp(rng, api, oracle, _lib, ctx, pool, batch):
+    n = int(batch["n_pairs"])
+    kw = dict(tuple_size=int(rng.integers(4, 16)), ins=int(rng.integers(0, 21)), dele=int(rng.integers(0, 21)),
+              match=int(rng.integers(1, 11)), max_fragments=int(rng.choice([16, 64, 256, 1024, 4096])))
+    st, sc, nb, off, blocks, rc = ctx.sdp_host(batch, api.make_sdp_params(**kw))
+    if rc != 0:
+        return (0, "sdp_rc", 0, rc), kw
+    OP = oracle.make_sdp_params(k=kw["tuple_size"], ins=kw["ins"], dele=kw["dele"], match=kw["match"], max_fragments=kw["max_fragments"])
+    chunk = max(1, n // 16)
+    futs = [(f, pool.submit(oracle.sdp_chain_batch, batch, OP, f, min(chunk, n - f))) for f in range(0, n, chunk)]
+    for f0, fu in futs:
+        est, enb, esc, _, eb = fu.result()
+        for i in range(len(est)):
+            p = f0 + i
+            if int(st[p]) == _lib.PAIR_TOO_LONG and int(est[i]) == _lib.PAIR_TOO_LONG:
+                continue
+            if (int(st[p]), int(nb[p]), int(sc[p])) != (int(est[i]), int(enb[i]), int(esc[i])):
+                return (p, "sdp", (int(est[i]), int(enb[i]), int(esc[i])), (int(st[p]), int(nb[p]), int(sc[p]))), kw
+            got = blocks[int(off[p]):int(off[p]) + int(nb[p])]
+            if not (np.array_equal(got["q_pos"], eb[i]["q_pos"]) and np.array_equal(got["t_pos"], eb[i]["t_pos"]) and np.array_equal(got["length"], eb[i]["length"])):
+                return (p, "sdp_blocks", len(eb[i]), len(got)), kw
+    return None, kw
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
     import util
-    from blasr_amd import api, synth, _lib
+    from blasr_amd import api, synth, _lib, emit
     from oracle import oracle
     rng = np.random.default_rng(args.seed)
     ctx = api.Context(0)
     pool = ThreadPoolExecutor(16)
     t_end = time.time() + args.seconds
-    rounds = pairs_done = fails = unsupported = 0
+    rounds = pairs_done = fails = unsupported = cigar_rounds = sdp_rounds = 0
     hist = {}
     modes = {}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -108,7 +166,13 @@ def main():
                 unsupported += 1
                 continue
             raise
-        pairs, blocks, rc = ctx.refine_host(batch)
+        cig = None
+        if rounds % 2 == 1:
+            cig_flags = int(rng.integers(0, 4))
+            pairs, blocks, ops, off, rc = ctx.refine_host_cigar(batch, flags=cig_flags)
+            cig = (ops, off, cig_flags)
+        else:
+            pairs, blocks, rc = ctx.refine_host(batch)
         assert rc == 0
         P = oracle.make_params(**kw)
         chunk = max(1, n // 16)
@@ -137,6 +201,14 @@ def main():
             if len(kb) != len(ob) or not (np.array_equal(kb["q_pos"], ob["q_pos"]) and np.array_equal(kb["t_pos"], ob["t_pos"])
                                           and np.array_equal(kb["length"], ob["length"])):
                 bad = (p, "blocks", len(ob), len(kb)); break
+        if not bad and cig is not None:
+            bad = check_cigars(rng, emit, _lib, batch, pairs, blocks, cig[0], cig[1], cig[2])
+            cigar_rounds += 1
+        if not bad and rounds % 3 == 2:
+            bad, skw = check_sdp(rng, api, oracle, _lib, ctx, pool, batch)
+            sdp_rounds += 1
+            if bad:
+                kw = dict(kw, sdp=skw)
         rounds += 1; pairs_done += n
         for v, c in zip(*np.unique(pairs["status"], return_counts=True)):
             hist[int(v)] = hist.get(int(v), 0) + int(c)
@@ -159,7 +231,7 @@ def main():
         if rounds % 20 == 0:
             print("rounds %d pairs %d fails %d unsupported-scoring %d" % (rounds, pairs_done, fails, unsupported), flush=True)
     print("DONE rounds %d pairs %d fails %d unsupported-scoring %d" % (rounds, pairs_done, fails, unsupported), flush=True)
-    print("status histogram", hist, "pairs per mode", modes, flush=True)
+    print("status histogram", hist, "pairs per mode", modes, "rounds with CIGAR check", cigar_rounds, "rounds with guide production", sdp_rounds, flush=True)
     sys.exit(1 if fails else 0)
 
 

@@ -172,3 +172,16 @@ def test_host_mirror_guides_then_refine(api, oracle, synth):
             assert len(c.blocks) == len(rb) and (c.blocks["length"] == rb["length"]).all()
     finally:
         ctx.close()
+
+
+def test_recorded_fuzz_mismatches(api, oracle):
+    """Every pair on which a randomised run once disagreed with the oracle, replayed."""
+    import json, os, util
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sdp_fuzz_regressions.json")))["cases"]
+    ctx = api.Context(0)
+    try:
+        for c in cases:
+            batch = util.make_batch([(c["q"].encode("latin1"), c["t"].encode("latin1"), [(0, 0, 1)])] * 3)
+            _compare(api, oracle, ctx, batch, **c["sdp"])
+    finally:
+        ctx.close()
