@@ -1692,6 +1692,7 @@ struct SdpConst {
     uint32_t hit_limit;           // more k-mer hits than this in one pair: too repetitive
     uint32_t tile, slots_log2;    // target positions indexed at a time; log2 of the hash slots (= 2 * tile)
     uint32_t qwords, twords;      // dwords of a packed sequence (including two pad words)
+    uint32_t queue;               // hits queued per tile before they are worked on
     uint32_t stop;                // experiments: leave the kernel after this phase (0: run it all)
 };
 
@@ -1738,7 +1739,7 @@ __global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(Dev d, SdpConst sc, c
                                                              uint2 *frags, uint32_t *nfrag)
 {
     extern __shared__ uint32_t smem[];
-    __shared__ uint32_t s_nfrag, s_hits;
+    __shared__ uint32_t s_nfrag, s_hits, s_nq;
     const uint32_t p = blockIdx.x, tid = threadIdx.x;
     const uint32_t SLOTS = 1u << sc.slots_log2;
     // LDS: hash slots (SLOTS dwords: tag << 16 | head of the k-mer's list) | next (u16 x tile) | query bases, query marks,
@@ -1747,7 +1748,8 @@ __global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(Dev d, SdpConst sc, c
     // has moved off its home slot is no longer identified by slot and tag.
     uint32_t *tab = smem;
     unsigned short *nxt = (unsigned short *)(smem + SLOTS);
-    uint32_t *qp = smem + SLOTS + sc.tile / 2, *qs = qp + sc.qwords, *tp = qs + sc.qwords, *ts = tp + sc.twords;
+    uint32_t *hq = smem + SLOTS + sc.tile / 2;                            // queue of hits: query position << 16 | list head
+    uint32_t *qp = hq + sc.queue, *qs = qp + sc.qwords, *tp = qs + sc.qwords, *ts = tp + sc.twords;
 
     int st = d.status[p];
     const uint32_t Q = d.Q[p], T = d.T[p];
@@ -1786,13 +1788,38 @@ __global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(Dev d, SdpConst sc, c
     const uint32_t kmark = (uint32_t)((1ull << kbits) - 1ull) & 0x55555555u;
     const uint32_t hshift = kbits - sc.slots_log2;                        // (the tuple has at least log2(SLOTS) bits: run_sdp sees to it)
     uint2 *myfrags = frags + (uint64_t)p * sc.cap;
+    // hits of the query position x with the list of target positions that starts at v (tile-relative, + 1)
+    auto process = [&](uint32_t x, uint32_t v, uint32_t tile0) {
+        uint32_t hits = 0;
+        for (; v; v = nxt[v - 1u]) {
+            const uint32_t y = tile0 + v - 1u;
+            hits++;
+            // the start of its run? (the cell one step back on the diagonal is no match)
+            if (x > 0u && y > 0u) {
+                const uint32_t a = window16(qp, x - 1u), b = window16(tp, y - 1u), m = window16(qs, x - 1u) | window16(ts, y - 1u);
+                if ((((a ^ b) | m) & 3u) == 0u) continue;
+            }
+            uint32_t len = sc.k;
+            for (;;) {
+                const uint32_t a = window16(qp, x + len), b = window16(tp, y + len), m = window16(qs, x + len) | window16(ts, y + len);
+                const uint32_t df = a ^ b;
+                const uint32_t bad = ((df | df >> 1) | m) & 0x55555555u;
+                if (bad) { len += (uint32_t)__builtin_ctz(bad) >> 1; break; }
+                len += 16u;
+            }
+            const uint32_t at = atomicAdd(&s_nfrag, 1u);
+            if (at < sc.cap) myfrags[at] = make_uint2(x << 16 | y, len);
+        }
+        atomicAdd(&s_hits, hits);
+    };
     // ---- one tile of the target at a time
     // (Measured alternatives, all slower on 10-kb reads: k-mers rolled through registers along per-thread stretches, lanes
-    // of a wave probing out of step with their hits queued for later, four independent positions per thread in flight.
-    // The kernel is bound by the instructions it issues, about 30 000 per wave and pair, not by LDS latency or conflicts.)
+    // of a wave probing out of step, four independent positions per thread in flight.  The kernel is bound by the
+    // instructions it issues, not by LDS latency or conflicts.)
     for (uint32_t tile0 = 0; tile0 + sc.k <= T; tile0 += sc.tile) {
         __syncthreads();
         for (uint32_t i = tid; i < SLOTS; i += SDP_THREADS) tab[i] = 0;
+        if (tid == 0) s_nq = 0;
         __syncthreads();
         const uint32_t tend = min(tile0 + sc.tile, T - sc.k + 1u);        // k-mers start in [tile0, tend)
         for (uint32_t y = tile0 + tid; y < tend; y += SDP_THREADS) {
@@ -1831,28 +1858,17 @@ __global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(Dev d, SdpConst sc, c
                 if ((v >> 16 ^ mix) << 16 == 0u && (window16(tp, tile0 + (v & 0xffffu) - 1u) & sc.kmask) == km) { v &= 0xffffu; break; }
                 h = (h + 1u) & (SLOTS - 1u);
             }
-            uint32_t hits = 0;
-            for (; v; v = nxt[v - 1u]) {
-                const uint32_t y = tile0 + v - 1u;
-                hits++;
-                // the start of its run? (the cell one step back on the diagonal is no match)
-                if (x > 0u && y > 0u) {
-                    const uint32_t a = window16(qp, x - 1u), b = window16(tp, y - 1u), m = window16(qs, x - 1u) | window16(ts, y - 1u);
-                    if ((((a ^ b) | m) & 3u) == 0u) continue;
-                }
-                uint32_t len = sc.k;
-                for (;;) {
-                    const uint32_t a = window16(qp, x + len), b = window16(tp, y + len), m = window16(qs, x + len) | window16(ts, y + len);
-                    const uint32_t df = a ^ b;
-                    const uint32_t bad = ((df | df >> 1) | m) & 0x55555555u;
-                    if (bad) { len += (uint32_t)__builtin_ctz(bad) >> 1; break; }
-                    len += 16u;
-                }
-                const uint32_t at = atomicAdd(&s_nfrag, 1u);
-                if (at < sc.cap) myfrags[at] = make_uint2(x << 16 | y, len);
+            // a hit is queued and worked on after the loop, one hit per thread (in the loop a wave would run the whole of
+            // the hit code at nearly every position for the few lanes that have one); a full queue: at once
+            if (v) {
+                const uint32_t qi = atomicAdd(&s_nq, 1u);
+                if (qi < sc.queue) hq[qi] = x << 16 | v;
+                else process(x, v, tile0);
             }
-            if (hits) atomicAdd(&s_hits, hits);
         }
+        __syncthreads();
+        const uint32_t nq = min(*(volatile uint32_t *)&s_nq, sc.queue);
+        for (uint32_t i = tid; i < nq; i += SDP_THREADS) process(hq[i] >> 16, hq[i] & 0xffffu, tile0);
     }
     __syncthreads();
     if (tid == 0) {
@@ -2043,6 +2059,7 @@ struct gba_ctx {
     // per indexed position (env GBA_SDP_SLOTS: 2 or 4).  Measured on 32 768 pairs of 10 kb, whole guide production:
     // 2048 x 4: 13.7 ms; 1024 x 4: 14.2; 4096 x 2: 15.1; 2048 x 2: 15.3; 4096 x 4: 22.9; 8192 x 2: 25.5 (LDS for one
     // workgroup per CU only)
+    uint32_t sdp_queue = 1024;       // hits queued per tile (env GBA_SDP_QUEUE, 64..16384)
     uint32_t sdp_tile_max = 2048;
     uint32_t sdp_slots_per_pos = 4;
     gba_scoring sc;
@@ -2628,8 +2645,9 @@ int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides
         while (k.slots_log2 > 2u * k.k) k.slots_log2--;                 // short tuples: no more slots than k-mers exist
         k.qwords = maxQ / 16 + 3; k.twords = maxT / 16 + 3;
         size_t lds;
+        k.queue = c->sdp_queue;
         for (;;) {
-            lds = ((size_t)(1u << k.slots_log2) + k.tile / 2 + 2 * (size_t)(k.qwords + k.twords)) * 4;
+            lds = ((size_t)(1u << k.slots_log2) + k.tile / 2 + k.queue + 2 * (size_t)(k.qwords + k.twords)) * 4;
             if (lds <= 160 * 1024 - 256 || k.tile <= 1024) break;
             k.tile >>= 1; k.slots_log2--;                                   // long sequences leave less room for the table
         }
@@ -2709,6 +2727,7 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
             const uint32_t v = (uint32_t)strtoul(e, nullptr, 10);
             if (v >= 1024 && v <= 16384 && (v & (v - 1)) == 0) c->sdp_tile_max = v;
         }
+        if (const char *e = getenv("GBA_SDP_QUEUE")) { const int v = atoi(e); if (v >= 64 && v <= 16384) c->sdp_queue = (uint32_t)v; }
         if (const char *e = getenv("GBA_SDP_SLOTS")) { const int v = atoi(e); if (v == 2 || v == 4) c->sdp_slots_per_pos = (uint32_t)v; }
         for (int h = 0; h < NSLOT && !rc; h++) {
             Slot &sl = c->slot[h];

@@ -7,9 +7,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 batch, cfg = synth.preset("c2_10kb_linear", n)
 db = api.to_device(batch)
 sp = api.make_sdp_params()
-for tile, slots, stop in [(2048, 4, 5), (2048, 4, 2), (2048, 4, 0), (4096, 2, 0), (4096, 4, 0), (2048, 2, 0), (1024, 4, 0), (8192, 2, 0)]:
+for tile, slots, queue, stop in [(2048, 4, 1024, 5), (2048, 4, 1024, 2), (2048, 4, 1024, 0), (2048, 4, 512, 0), (4096, 2, 1024, 0), (4096, 2, 2048, 0), (4096, 4, 2048, 0), (1024, 4, 512, 0)]:
     os.environ["GBA_SDP_TILE"] = str(tile)
     os.environ["GBA_SDP_SLOTS"] = str(slots)
+    os.environ["GBA_SDP_QUEUE"] = str(queue)
     os.environ["GBA_SDP_STOP"] = str(stop)
     ctx = api.Context(0)
     g = ctx.sdp_device(db, sp)
@@ -18,5 +19,5 @@ for tile, slots, stop in [(2048, 4, 5), (2048, 4, 2), (2048, 4, 0), (4096, 2, 0)
     for _ in range(3):
         g = ctx.sdp_device(db, sp)
     torch.cuda.synchronize()
-    print("tile=%d slots=%d stop=%d  %.2f ms per %d pairs" % (tile, slots, stop, (time.perf_counter() - t0) / 3 * 1e3, n), flush=True)
+    print("tile=%d slots=%d queue=%d stop=%d  %.2f ms per %d pairs" % (tile, slots, queue, stop, (time.perf_counter() - t0) / 3 * 1e3, n), flush=True)
     ctx.close()
