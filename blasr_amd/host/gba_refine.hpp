@@ -33,6 +33,8 @@ struct MappingParameters {
     bool doGlobalAlignment = false;
     int maxScore = -200;
     int tieBreak = GBA_TIE_DIAG_LEFT_UP;
+    int sdpTupleSize = 11, sdpIns = 5, sdpDel = 10;     // :220-222
+    uint32_t sdpMaxFragments = 1024;                    // not a BLASR option: the device's budget of maximal matches per candidate
 };
 
 // the T_AlignmentCandidate fields RefineAlignment reads and writes (:678-772)
@@ -242,6 +244,53 @@ private:
     std::vector<uint32_t> q_len_, t_len_, n_blk_;
     bool have_last_ = false; size_t last_len_ = 0; uint64_t last_base_ = 0;
 };
+
+// The guide of every candidate of a read in one call: what AlignIntervals does per candidate with
+// SDPAlign(alignment->qAlignedSeq, alignment->tAlignedSeq, distScoreFn, sdpTupleSize, params.sdpIns, params.sdpDel,
+// params.indelRate*3, *alignment, mappingBuffers, Local, ...) (iblasr/BlasrAlignImpl.hpp:980-987).  The query is the read
+// from qAlignedSeqPos on (qAlignedSeqLength bases, the rest of the read when that is 0), the target the candidate's
+// window.  On return blocks are relative to the first block and qPos / tPos give its start (:951-964); a candidate
+// without a single match of sdpTupleSize bases keeps no blocks; score is minus the chain's score (lower is better).
+inline int SDPAlignCandidates(const std::string &read, std::vector<AlignmentCandidate *> &alignmentPtrs,
+                              const MappingParameters &params, gba_ctx *ctx)
+{
+    const uint32_t n = (uint32_t)alignmentPtrs.size();
+    if (n == 0) return GBA_OK;
+    std::string t_arena;
+    std::vector<uint64_t> q_off(n), t_off(n), blk_off(n);
+    std::vector<uint32_t> q_len(n), t_len(n), n_blk(n);
+    std::vector<int32_t> status(n), score(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const AlignmentCandidate &c = *alignmentPtrs[i];
+        if (c.qAlignedSeqPos > read.size()) throw std::out_of_range("candidate starts behind its read");
+        q_off[i] = c.qAlignedSeqPos;
+        q_len[i] = c.qAlignedSeqLength ? c.qAlignedSeqLength : (uint32_t)(read.size() - c.qAlignedSeqPos);
+        t_off[i] = t_arena.size(); t_len[i] = (uint32_t)c.tAlignedSeq.size();
+        t_arena += c.tAlignedSeq;
+    }
+    if (t_arena.empty()) t_arena.push_back('N');
+    gba_batch b{};
+    b.n_pairs = n;
+    b.q_arena = (const uint8_t *)read.data(); b.q_off = q_off.data(); b.q_len = q_len.data(); b.q_arena_bytes = read.size();
+    b.t_arena = (const uint8_t *)t_arena.data(); b.t_off = t_off.data(); b.t_len = t_len.data(); b.t_arena_bytes = t_arena.size();
+    gba_sdp_params sp{params.sdpTupleSize, params.sdpIns, params.sdpDel, -params.match, params.sdpMaxFragments};
+    std::vector<gba_block> blocks((size_t)n * params.sdpMaxFragments);
+    gba_guides g{status.data(), score.data(), n_blk.data(), blk_off.data(), blocks.data(), blocks.size(), 0};
+    const int rc = gba_sdp(ctx, &b, &sp, &g);
+    if (rc != GBA_OK) return rc;
+    for (uint32_t i = 0; i < n; i++) {
+        AlignmentCandidate &c = *alignmentPtrs[i];
+        c.status = status[i];
+        c.blocks.clear();
+        c.qPos = c.tPos = 0;
+        c.score = -score[i];
+        if (status[i] != GBA_PAIR_OK || n_blk[i] == 0) continue;
+        const gba_block *src = blocks.data() + blk_off[i];
+        c.qPos = src[0].q_pos; c.tPos = src[0].t_pos;
+        for (uint32_t k = 0; k < n_blk[i]; k++) c.blocks.push_back(Block{src[k].q_pos - c.qPos, src[k].t_pos - c.tPos, src[k].length});
+    }
+    return GBA_OK;
+}
 
 // The -global branch of RefineAlignment (:648-675) for all candidates of one read: the whole subread
 // against the whole tAlignedSeq in a diagonal band of half-width ComputeDrift(candidate), RemoveEndGaps,

@@ -7,6 +7,7 @@
 //   reuse    hand every read to RefineBatch::Add through ONE std::string buffer that is overwritten
 //            for each candidate (what a parsing loop does)
 //   global   run the -global branch (RefineGlobal) on each (read, candidate) instead
+//   sdp      the guides come from the device first (SDPAlignCandidates: the blocks of the input are ignored), then the batch
 //   mapqv    no GPU: stdin is n, then "qStart qEnd rawProbScore" per candidate of ONE read; prints their mapQVs
 #include <cstdio>
 #include <iostream>
@@ -16,7 +17,7 @@
 int main(int argc, char **argv)
 {
     const std::string mode = argc > 1 ? argv[1] : "";
-    const bool cigar = mode == "cigar", reuse = mode == "reuse", global = mode == "global";
+    const bool cigar = mode == "cigar", reuse = mode == "reuse", global = mode == "global", sdp = mode == "sdp";
     size_t n;
     if (!(std::cin >> n)) return 2;
     if (mode == "mapqv") {
@@ -56,6 +57,13 @@ int main(int argc, char **argv)
             rc = gba::RefineAlignments(reads[i], one, params, ctx);
         }
     } else {
+        if (sdp) {
+            for (size_t i = 0; i < n && rc == GBA_OK; i++) {
+                std::vector<gba::AlignmentCandidate *> one{&cands[i]};
+                rc = gba::SDPAlignCandidates(reads[i], one, params, ctx);
+            }
+            if (rc != GBA_OK) { std::fprintf(stderr, "SDPAlignCandidates: %s\n", gba_strerror(rc)); return 1; }
+        }
         gba::RefineBatch batch(ctx);
         std::string buffer;
         for (size_t i = 0; i < n; i++) {

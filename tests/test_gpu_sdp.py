@@ -185,3 +185,31 @@ def test_recorded_fuzz_mismatches(api, oracle):
             _compare(api, oracle, ctx, batch, **c["sdp"])
     finally:
         ctx.close()
+
+
+def test_block_arena_too_small_and_long_reads(api, oracle, synth):
+    """NOSPACE: the count is still reported, pairs that fit are complete, the others are flagged.  And a
+    batch of 50-kb reads with a fragment budget that fits them (the default 1024 is for reads up to ~30 kb)."""
+    import torch
+    from blasr_amd import _lib
+    ctx = api.Context(0)
+    try:
+        batch = synth.generate(40, read_len=3000, seed=51)
+        db = api.to_device(batch)
+        full = ctx.sdp_device(db, api.make_sdp_params())
+        st, sc, nb, off, blocks = _guides_to_host(full)
+        assert full["rc"] == 0 and (st == 0).all()
+        cap = int(off[25])
+        g = ctx.sdp_device(db, api.make_sdp_params(), blocks_capacity=cap)
+        torch.cuda.synchronize()
+        assert g["rc"] == _lib.E_NOSPACE and g["blocks_needed"] == full["blocks_needed"]
+        st2, _, nb2, off2, blocks2 = _guides_to_host(g)
+        assert (st2[:25] == 0).all() and (st2[25:] == _lib.PAIR_NOSPACE).all() and (off2 == off).all() and (nb2 == nb).all()
+        assert (blocks2[:cap] == blocks[:cap]).all()
+        long_batch, _ = synth.preset("c5_50kb_wide", 6)
+        st, _ = _compare(api, oracle, ctx, long_batch, max_fragments=4096)
+        assert (st == 0).all()
+        st, _ = _compare(api, oracle, ctx, long_batch, max_fragments=512)
+        assert (st == _lib.PAIR_TOO_MANY).all()
+    finally:
+        ctx.close()

@@ -216,3 +216,34 @@ def test_cpp_host_shim_matches_oracle(oracle, synth):
         kw = dict(q_pos=int(er["q_pos"]), t_pos=int(er["t_pos"]))
         assert cig_merged == emit.cigar(eb, bytes(q), bytes(t), **kw)
         assert cig_adjacent == emit.cigar(eb, bytes(q), bytes(t), allow_adjacent_indels=True, **kw)
+
+
+@pytest.mark.gpu
+def test_cpp_guides_then_refine_matches_the_oracles(oracle, synth):
+    """refine_demo sdp: gba::SDPAlignCandidates makes the guide of every candidate, RefineBatch refines it;
+    against the two oracles run one after the other on the same sequences."""
+    from blasr_amd import build
+    exe = build.HOST_DEMO
+    assert os.path.exists(exe), "run python -m blasr_amd.build"
+    batch = synth.generate(8, read_len=1500, len_jitter=500, seed=77)
+    lines = ["8"]
+    for i in range(8):
+        q, t, _ = synth.pair(batch, i)
+        lines.append("%s %s 0" % (bytes(q).decode(), bytes(t).decode()))
+    out = subprocess.run([exe, "sdp"], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rows = out.stdout.strip().split("\n")
+    assert len(rows) == 8
+    for i, row in enumerate(rows):
+        v = [int(x) for x in row.split()]
+        q, t, _ = synth.pair(batch, i)
+        q, t = bytes(q), bytes(t)
+        st, guide, _, _ = oracle.sdp_chain(q, t, oracle.make_sdp_params(max_fragments=1024))
+        assert st == 0
+        q0, t0 = int(guide[0]["q_pos"]), int(guide[0]["t_pos"])
+        g = guide.copy(); g["q_pos"] -= np.uint32(q0); g["t_pos"] -= np.uint32(t0)
+        ql, tl = int(g[-1]["q_pos"]) + int(g[-1]["length"]), int(g[-1]["t_pos"]) + int(g[-1]["length"])
+        er, eb = oracle.align(q[q0:q0 + ql], t[t0:t0 + tl], g, oracle.make_params())
+        assert v[:6] == [0, er["score"], er["ncells"], er["q_pos"], er["t_pos"], er["n_blk"]]
+        got = np.array(v[6:]).reshape(-1, 3)
+        assert np.array_equal(got[:, 0], eb["q_pos"]) and np.array_equal(got[:, 1], eb["t_pos"]) and np.array_equal(got[:, 2], eb["length"])
