@@ -1682,7 +1682,7 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_ops(Dev d, uint64_t *carry, uin
 // bases at a time and become fragments.  The fragments are sorted in LDS (bitonic), then one wave
 // chains them: 64 fragments per round, every lane scanning all earlier fragments (uniform LDS
 // reads), the 64 of the round settling among themselves lane by lane.
-constexpr uint32_t SDP_THREADS = 256;
+constexpr uint32_t SDP_THREADS = 512;       // eight waves per pair: with three pairs per CU (47 KB of LDS each) 24 waves hide the table's latency (256: 13.3 ms per 32 768 pairs of 10 kb, 512: 9.7, 1024: 13.3)
 typedef uint32_t u32x4u1 __attribute__((ext_vector_type(4), aligned(1)));
 
 struct SdpConst {
@@ -1930,7 +1930,14 @@ __global__ __launch_bounds__(64) void k_sdp_chain(SdpConst sc, const uint2 *frag
             const int32_t g = (int32_t)pr.z - max(dd * DEL, -dd * INS) - o * M;
             if (allowed && o < pl && g > best) { best = g; bp = pidx; }
         };
-        for (uint32_t q0 = 0; q0 < b0; q0++) relax(F[q0], q0, true);
+        // (b0 is a multiple of 64) eight earlier fragments per turn: their LDS reads travel together
+        for (uint32_t q0 = 0; q0 < b0; q0 += 8) {
+            uint4 pr[8];
+#pragma unroll
+            for (int z = 0; z < 8; z++) pr[z] = F[q0 + z];
+#pragma unroll
+            for (int z = 0; z < 8; z++) relax(pr[z], q0 + z, true);
+        }
         // the fragments of this round among themselves: lane j is final once lanes 0..j-1 have been offered to it
         const uint32_t lim = min(64u, n - b0);
         for (uint32_t j = 0; j < lim; j++) {
@@ -2056,9 +2063,8 @@ struct gba_ctx {
     bool lds_attr_set = false;       // the fill kernels' dynamic-LDS limit has been raised on this device
     bool sdp_attr_set = false;       // the same for k_sdp
     // k_sdp_match: target positions indexed at a time, at most (env GBA_SDP_TILE; power of two, 1024..16384), and hash slots
-    // per indexed position (env GBA_SDP_SLOTS: 2 or 4).  Measured on 32 768 pairs of 10 kb, whole guide production:
-    // 2048 x 4: 13.7 ms; 1024 x 4: 14.2; 4096 x 2: 15.1; 2048 x 2: 15.3; 4096 x 4: 22.9; 8192 x 2: 25.5 (LDS for one
-    // workgroup per CU only)
+    // per indexed position (env GBA_SDP_SLOTS: 2 or 4).  Measured on 32 768 pairs of 10 kb, whole guide production, 512
+    // threads per pair: 2048 x 4: 9.7 ms; 4096 x 2: 13.1; 4096 x 4: 14.1; 8192 x 2: 16.3
     uint32_t sdp_queue = 1024;       // hits queued per tile (env GBA_SDP_QUEUE, 64..16384)
     uint32_t sdp_tile_max = 2048;
     uint32_t sdp_slots_per_pos = 4;
@@ -2640,7 +2646,7 @@ int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides
         hipLaunchKernelGGL(k_pack, dim3(cnt), dim3(256), 0, s, d);
         hipLaunchKernelGGL(k_pack_q, dim3(cnt), dim3(256), 0, s, d, qcodes);
         // the target is indexed a tile at a time: a tile of half the hash slots, sized to the longest window (up to SDP_TILE_MAX)
-        k.tile = 1024; while (k.tile < maxT && k.tile < c->sdp_tile_max) k.tile <<= 1;
+        k.tile = 256; while (k.tile < maxT && k.tile < c->sdp_tile_max) k.tile <<= 1;
         k.slots_log2 = 1; while ((1u << k.slots_log2) < c->sdp_slots_per_pos * k.tile) k.slots_log2++;
         while (k.slots_log2 > 2u * k.k) k.slots_log2--;                 // short tuples: no more slots than k-mers exist
         k.qwords = maxQ / 16 + 3; k.twords = maxT / 16 + 3;
@@ -2648,7 +2654,7 @@ int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides
         k.queue = c->sdp_queue;
         for (;;) {
             lds = ((size_t)(1u << k.slots_log2) + k.tile / 2 + k.queue + 2 * (size_t)(k.qwords + k.twords)) * 4;
-            if (lds <= 160 * 1024 - 256 || k.tile <= 1024) break;
+            if (lds <= 160 * 1024 - 256 || k.tile <= 256) break;
             k.tile >>= 1; k.slots_log2--;                                   // long sequences leave less room for the table
         }
         if (lds > 160 * 1024 - 256) return GBA_E_UNSUPPORTED;
@@ -2725,10 +2731,10 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
         if (const char *e = getenv("GBA_WAVE_PAIRS_AFFINE")) c->wave_pairs_affine = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_SDP_TILE")) {
             const uint32_t v = (uint32_t)strtoul(e, nullptr, 10);
-            if (v >= 1024 && v <= 16384 && (v & (v - 1)) == 0) c->sdp_tile_max = v;
+            if (v >= 256 && v <= 16384 && (v & (v - 1)) == 0) c->sdp_tile_max = v;
         }
         if (const char *e = getenv("GBA_SDP_QUEUE")) { const int v = atoi(e); if (v >= 64 && v <= 16384) c->sdp_queue = (uint32_t)v; }
-        if (const char *e = getenv("GBA_SDP_SLOTS")) { const int v = atoi(e); if (v == 2 || v == 4) c->sdp_slots_per_pos = (uint32_t)v; }
+        if (const char *e = getenv("GBA_SDP_SLOTS")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) c->sdp_slots_per_pos = (uint32_t)v; }
         for (int h = 0; h < NSLOT && !rc; h++) {
             Slot &sl = c->slot[h];
             if (h == 0) sl.s = c->stream;

@@ -7,7 +7,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 batch, cfg = synth.preset("c2_10kb_linear", n)
 db = api.to_device(batch)
 sp = api.make_sdp_params()
-for tile, slots, queue, stop in [(2048, 4, 1024, 5), (2048, 4, 1024, 2), (2048, 4, 1024, 0), (2048, 4, 512, 0), (4096, 2, 1024, 0), (4096, 2, 2048, 0), (4096, 4, 2048, 0), (1024, 4, 512, 0)]:
+for tile, slots, queue, stop in [(2048, 4, 1024, 2), (2048, 4, 1024, 3), (2048, 4, 1024, 4), (2048, 4, 1024, 0)]:
     os.environ["GBA_SDP_TILE"] = str(tile)
     os.environ["GBA_SDP_SLOTS"] = str(slots)
     os.environ["GBA_SDP_QUEUE"] = str(queue)
