@@ -1881,17 +1881,21 @@ __global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(Dev d, SdpConst sc, c
 
 // Chain of one pair: one wave.  Sorts the pair's fragments in LDS, settles them 64 at a time, traces the best chain
 // back and writes its blocks to chains + pair * max_fragments.
+// Launched twice: for the pairs with at most SDP_SMALL fragments with LDS for that many (more waves per CU: most pairs of
+// 10-kb reads have ~300), and for the others with LDS for the whole budget; a wave leaves at once when its pair is not of its launch.
+constexpr uint32_t SDP_SMALL = 512;
 __global__ __launch_bounds__(64) void k_sdp_chain(SdpConst sc, const uint2 *frags, const uint32_t *nfrag, int32_t *out_score,
-                                                   uint32_t *out_nblk, gba_block *chains)
+                                                   uint32_t *out_nblk, gba_block *chains, uint32_t n_above, uint32_t n_upto)
 {
     extern __shared__ uint32_t smem[];
     uint4 *F = (uint4 *)(((uintptr_t)smem + 15u) & ~(uintptr_t)15u);      // .x = query start << 16 | target start, .y = length, .z = score, .w = predecessor
     const uint32_t p = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = nfrag[p];
     if (n == 0u) {
-        if (tid == 0) { out_score[p] = 0; out_nblk[p] = 0; }
+        if (tid == 0 && n_above == 0u) { out_score[p] = 0; out_nblk[p] = 0; }
         return;
     }
+    if (n <= n_above || n > n_upto) return;
     uint32_t P2 = 1;
     while (P2 < n) P2 <<= 1;
     {
@@ -2662,8 +2666,14 @@ int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides
         uint32_t *nfrag = d.span;                  // a spare per-pair array
         hipLaunchKernelGGL(k_sdp_match, dim3(cnt), dim3(SDP_THREADS), lds, s, d, k, (const uint8_t *)qcodes, out->status + first,
                            (uint2 *)sl.b_guide.ptr, nfrag);
-        hipLaunchKernelGGL(k_sdp_chain, dim3(cnt), dim3(64), (size_t)k.cap * 16 + 16, s, k, (const uint2 *)sl.b_guide.ptr, (const uint32_t *)nfrag,
-                           out->chain_score + first, out->n_blk + first, (gba_block *)sl.b_blk.ptr);
+        {
+            const uint32_t small = k.cap < SDP_SMALL ? k.cap : SDP_SMALL;
+            hipLaunchKernelGGL(k_sdp_chain, dim3(cnt), dim3(64), (size_t)small * 16 + 16, s, k, (const uint2 *)sl.b_guide.ptr, (const uint32_t *)nfrag,
+                               out->chain_score + first, out->n_blk + first, (gba_block *)sl.b_blk.ptr, 0u, small);
+            if (k.cap > small)
+                hipLaunchKernelGGL(k_sdp_chain, dim3(cnt), dim3(64), (size_t)k.cap * 16 + 16, s, k, (const uint2 *)sl.b_guide.ptr, (const uint32_t *)nfrag,
+                                   out->chain_score + first, out->n_blk + first, (gba_block *)sl.b_blk.ptr, small, k.cap);
+        }
         hipLaunchKernelGGL(k_scan_cnt, dim3(1), dim3(SCAN_T), 0, s, (const uint32_t *)(out->n_blk + first), out->blk_off + first, cnt, needed);
         hipLaunchKernelGGL(k_sdp_emit, dim3(cnt), dim3(256), 0, s, (const gba_block *)sl.b_blk.ptr, k.max_fragments,
                            (const uint32_t *)(out->n_blk + first), (const uint64_t *)(out->blk_off + first), out->blocks, out->blocks_capacity, out->status + first);
