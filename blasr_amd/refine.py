@@ -198,6 +198,26 @@ def SDPAlignCandidates(read: bytes, cands: List[AlignmentCandidate], params: Map
     return cands
 
 
+def GuidedAlignFromSequences(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx,
+                             bandSize: int = 12, sdpTupleSize: int = 6):
+    """The GuidedAlign overload that takes only the two sequences: it chains matches of sdpTupleSize
+    bases itself and runs the banded DP around that chain.  AlignSubreadToAlignmentTarget uses it to
+    align every subread of a ZMW to the window its CCS (or longest subread) mapped to:
+    GuidedAlign(subread, alignedRefSequence, idsScoreFn, 12, params.sdpIns, params.sdpDel,
+    params.indelRate, mappingBuffers, exploded, Local, computeProbIsFalse, 6)
+    (/root/reference/iblasr/BlasrAlignImpl.hpp:1418-1421), then ComputeAlignmentStats with
+    distScoreFn2 (:1448-1450).  Here: SDPAlignCandidates with the short tuple, then the refine stage
+    with band `bandSize`, all candidates of the read in one batch each.  What differs from that call
+    site: the DP runs on the distance matrix with params.insertion / params.deletion, not on the
+    QV-aware IDS scorer (its formulas are libcpp's and need per-base quality values), and it is
+    anchored at the chain's first and last block (the overload's Local end handling is libcpp's)."""
+    import dataclasses
+    p = dataclasses.replace(params, sdpTupleSize=sdpTupleSize, guidedAlignBandSize=bandSize, useGuidedAlign=True,
+                            doGlobalAlignment=False, refineAlignments=True)
+    SDPAlignCandidates(read, cands, p, ctx)
+    return RefineAlignments(read, cands, p, ctx)
+
+
 def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx):
     """Batched RefineAlignments (:905-923): all candidates of the read in one submit."""
     if not params.refineAlignments or not cands:

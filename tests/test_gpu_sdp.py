@@ -213,3 +213,30 @@ def test_block_arena_too_small_and_long_reads(api, oracle, synth):
         assert (st == _lib.PAIR_TOO_MANY).all()
     finally:
         ctx.close()
+
+
+def test_guided_align_from_sequences(api, oracle, synth):
+    """The composite the CCS path uses (chain of 6-mers, then a band of 12 around it) against the two
+    oracles run one after the other."""
+    from blasr_amd import refine
+    batch = synth.generate(4, read_len=1200, seed=61, p_ins=0.02, p_del=0.02, p_sub=0.01)
+    ctx = api.Context(0)
+    try:
+        params = refine.MappingParameters(sortRefinedAlignments=False, sdpMaxFragments=4096)
+        for p in range(4):
+            q, t, _ = synth.pair(batch, p)
+            read, window = bytes(q), bytes(t)
+            cands = [refine.AlignmentCandidate(tAlignedSeq=window)]
+            refine.GuidedAlignFromSequences(read, cands, params, ctx)
+            st, guide, _, _ = oracle.sdp_chain(read, window, oracle.make_sdp_params(k=6, max_fragments=4096))
+            assert st == 0 and cands[0].status == 0
+            q0, t0 = int(guide[0]["q_pos"]), int(guide[0]["t_pos"])
+            g = guide.copy(); g["q_pos"] -= np.uint32(q0); g["t_pos"] -= np.uint32(t0)
+            ql, tl = int(g[-1]["q_pos"]) + int(g[-1]["length"]), int(g[-1]["t_pos"]) + int(g[-1]["length"])
+            er, eb = oracle.align(read[q0:q0 + ql], window[t0:t0 + tl], g, oracle.make_params(band=12))
+            c = cands[0]
+            assert (c.score, c.nMatch, c.nMismatch, c.nIns, c.nDel) == (er["score"], er["n_match"], er["n_mismatch"], er["n_ins"], er["n_del"])
+            assert len(c.blocks) == len(eb) and (c.blocks["length"] == eb["length"]).all()
+            assert c.nMatch > 0.9 * len(read)
+    finally:
+        ctx.close()
