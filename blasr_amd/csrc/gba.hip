@@ -65,7 +65,8 @@ constexpr int PAD_SLOTS = 3;                 // spare slots behind a ring
 constexpr int SPAN_MARGIN = 4;               // a pair fits a class if its widest shift + width <= slots - SPAN_MARGIN (k_fill touches up to 7 slots past a row end)
 constexpr int CAP_LINEAR = 32, CAP_AFFINE = 40;   // cells per lane per step of k_fill (band 10 rows are 21+ cells, band 16 rows 33+)
 constexpr size_t ARENA_SLACK = 16384 + 256;          // bytes in front of the record / target-code arenas: k_traceback's windows start before a pair's data
-__host__ __device__ constexpr uint32_t cls_slots(int c) { return 32u << c; }
+// slots of lane class c: 32, 64, and a widest class of `top` slots (128 for linear gaps, 96 for affine)
+__host__ __device__ constexpr uint32_t cls_slots(int c, uint32_t top) { return c < 2 ? 32u << c : top; }
 
 // Guide stream words (one stream per pair, built by k_guide, consumed by k_fill):
 //   ROW  width[0:10) | query base code[10:13) | shift of the first column[13:23) | codes of the
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
 // `order` lists the OK pairs grouped by class (stable); rec_off is each pair's record offset in
 // dwords (4 spare dwords precede every pair: the traceback reads 16-byte windows ending at a row;
 // 12 follow it: the fill kernel stores whole steps and lets the next store overwrite the tail).  Pairs whose widest row needs more than the largest class are TOO_WIDE.
-__global__ __launch_bounds__(SCAN_T) void k_plan(Dev d, int ncls, int has_wide)
+__global__ __launch_bounds__(SCAN_T) void k_plan(Dev d, int ncls, int has_wide, uint32_t top_slots)
 {
     __shared__ uint64_t sm[17];
     __shared__ uint32_t cnt[NCLS + 1], base[NCLS + 1], cmap[NCLS + 1];
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(SCAN_T) void k_plan(Dev d, int ncls, int has_wide)
         uint32_t c = NCLS;
         if (d.status[p] == GBA_PAIR_OK) {
             const uint32_t s = d.span[p];
-            for (int k = ncls - 1; k >= 0; k--) if (s + SPAN_MARGIN <= cls_slots(k)) c = (uint32_t)k;
+            for (int k = ncls - 1; k >= 0; k--) if (s + SPAN_MARGIN <= cls_slots(k, top_slots)) c = (uint32_t)k;
             if (c == NCLS && has_wide) c = s <= WN_SPAN ? CLS_WNARROW : CLS_WIDE;
             if (c == NCLS) d.status[p] = GBA_PAIR_TOO_WIDE;
             else atomicAdd(&cnt[c], 1u);
@@ -2075,6 +2076,9 @@ struct gba_ctx {
     gba_scoring sc;
     FillConst fc;
     TbConst tbc;
+    uint32_t affine_top_slots = 0;   // affine gaps: a third lane class of this many slots (env GBA_AFFINE_TOP_SLOTS; 0: none).  Measured on 98 304 pairs
+                                     // of 20 kb, band 16 (99 % of them fit 96 slots): none 221 GCUPS, 96 slots 212, 80 slots 190, 128 slots 187: three
+                                     // lane-per-pair waves per CU are no faster than the narrow wave-per-pair kernel
     uint32_t wave_pairs = 20480, wave_pairs_affine = 57344;   // batches (parts) smaller than this run wave-per-pair (env GBA_WAVE_PAIRS, GBA_WAVE_PAIRS_AFFINE)
     uint32_t score_a = 0, score_b = 0;   // largest cost of a row move / of a move along a row (k_meta's score-range check)
     uint32_t part_pairs = 122880;    // a batch of more than ~1.07 x this many pairs is run in staggered parts of about this
@@ -2145,8 +2149,8 @@ void release(Buf &b)
 
 int launch_fill(gba_ctx *c, const Dev &d, uint32_t cls, uint32_t count, hipStream_t st)
 {
-    const uint32_t slots = cls_slots((int)cls);
     const bool aff = c->sc.mode == GBA_MODE_AFFINE;
+    const uint32_t slots = cls_slots((int)cls, aff ? c->affine_top_slots : 128u);
     const size_t rings = aff ? 2 : 1;
     const size_t lds = (rings * (slots + PAD_SLOTS) * 64 + LDS_TAB) * 4;
     if (!c->lds_attr_set) {                     // per device, and a ctx lives on one device
@@ -2207,8 +2211,9 @@ int phase_guide(gba_ctx *c, Slot &sl, Dev &d)
     // times the instructions per cell but fill the GPU from a few thousand pairs on.  Below wave_pairs
     // pairs the whole batch runs one wave per pair.
     const bool affine = sc.mode == GBA_MODE_AFFINE;
-    const int lane_classes = d.n < (affine ? c->wave_pairs_affine : c->wave_pairs) ? 0 : (affine ? LANE_CLS_AFFINE : LANE_CLS_LINEAR);
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(SCAN_T), 0, sl.s, d, lane_classes, 1);
+    const int lane_classes = d.n < (affine ? c->wave_pairs_affine : c->wave_pairs) ? 0
+                           : affine ? (c->affine_top_slots ? LANE_CLS_AFFINE + 1 : LANE_CLS_AFFINE) : LANE_CLS_LINEAR;
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(SCAN_T), 0, sl.s, d, lane_classes, 1, affine ? c->affine_top_slots : 128u);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(sl.h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, sl.s));
     return GBA_OK;
@@ -2739,6 +2744,7 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
         if (const char *e = getenv("GBA_PART_PAIRS")) c->part_pairs = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_WAVE_PAIRS")) c->wave_pairs = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_WAVE_PAIRS_AFFINE")) c->wave_pairs_affine = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char *e = getenv("GBA_AFFINE_TOP_SLOTS")) { const uint32_t v = (uint32_t)strtoul(e, nullptr, 10); if (v == 0 || (v > 64 && v <= 128)) c->affine_top_slots = v; }
         if (const char *e = getenv("GBA_SDP_TILE")) {
             const uint32_t v = (uint32_t)strtoul(e, nullptr, 10);
             if (v >= 256 && v <= 16384 && (v & (v - 1)) == 0) c->sdp_tile_max = v;
