@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 baseline on the box: GPU tests, copy rates, default bench, kernel trace, SQ counters of k_fill
+# baseline on the box: GPU tests, copy rates, default bench, kernel trace, SQ counters of k_fill
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/r02_gputests.log 2>&1 || { tail -30 gpurun_out/r02_gputests.log; exit 1; }

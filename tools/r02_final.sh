@@ -1,5 +1,5 @@
 #!/bin/bash
-# the round's closing measurements on the box: GPU suite, default bench line, kernel trace, counters of the fill kernel
+# closing measurements on the box: GPU suite, default bench line, kernel trace, counters of the fill kernel
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout -k 10 1000 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/r02_final_gputests.log 2>&1 || { tail -30 gpurun_out/r02_final_gputests.log; exit 1; }
