@@ -272,7 +272,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_guides:
         # The step in front of the path, on the same batch: guides made on the device from the sequences
         # alone (k-mer matches chained, gba_sdp_device), then the refine stage run on those guides.
-        sp = api.make_sdp_params()
+        sp = api.make_sdp_params(max_fragments=1024 if cfg["read_len"] <= 25_000 else 4096)      # ~31 maximal matches per kb at 15 % error
         g = ctx.sdp_device(dbatch, sp, blocks_capacity=cap)             # warm-up (scratch allocation)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
