@@ -88,8 +88,13 @@ def test_windows_of_a_resident_reference_on_both_strands(api, oracle, synth):
         batch = synth.generate(200, read_len=2500, seed=36, ref=ref, len_jitter=1000)
         assert 50 < int(batch["win_rc"].sum()) < 150
         ctx.set_reference(ref)
-        st, _ = _compare(api, oracle, ctx, batch, dbatch=api.to_device(synth.as_windows(batch)))
+        st, g = _compare(api, oracle, ctx, batch, dbatch=api.to_device(synth.as_windows(batch)))
         assert (st == 0).sum() > 190
+        # the same through the host-buffer entry point
+        hst, hsc, hnb, hoff, hblocks, rc = ctx.sdp_host(synth.as_windows(batch), api.make_sdp_params())
+        dst, dsc, dnb, doff, dblocks = _guides_to_host(g)
+        assert rc == 0 and (hst == dst).all() and (hsc == dsc).all() and (hnb == dnb).all() and (hoff == doff).all()
+        assert (hblocks == dblocks[:len(hblocks)]).all() and len(hblocks) == int(dnb.sum())
     finally:
         ctx.close()
 
