@@ -227,7 +227,8 @@ class Context:
         n = int(dbatch["n_pairs"])
         dev = dbatch["q_arena"].device
         if blocks_capacity is None:
-            blocks_capacity = max(1, int(dbatch["q_arena"].numel()) // 8 + n)
+            # a block per ~30 read bases at 15 % error; candidates of one read share its bytes, so count lengths, not the arena
+            blocks_capacity = max(1, int(dbatch["q_len"].to(torch.int64).sum().item()) // 8 + n)
         g = {"status": torch.zeros(n, dtype=torch.int32, device=dev), "chain_score": torch.zeros(n, dtype=torch.int32, device=dev),
              "n_blk": torch.zeros(n, dtype=torch.int32, device=dev), "blk_off": torch.zeros(n, dtype=torch.int64, device=dev),
              "blocks": torch.zeros((int(blocks_capacity), 3), dtype=torch.int32, device=dev)}
