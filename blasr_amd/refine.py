@@ -42,6 +42,7 @@ class MappingParameters:
     sdpIns: int = 5          # :220
     sdpDel: int = 10         # :221
     sdpMaxFragments: int = 1024   # not a BLASR option: the device's budget of maximal matches per candidate
+    sdpBypassThreshold: float = 1000000.0   # :340 (0.75 in the -sdpbypass preset, :721)
     scoreMatrix: Optional[list] = None     # 5x5, -scoreMatrix (Blasr.cpp:922-937)
 
 
@@ -195,6 +196,32 @@ def SDPAlignCandidates(read: bytes, cands: List[AlignmentCandidate], params: Map
             b["q_pos"] -= np.uint32(c.qPos); b["t_pos"] -= np.uint32(c.tPos)
         c.blocks = b
         c.score = -int(score[i])              # lower is better, like every score of the reference
+    return cands
+
+
+def GuidesFromAnchorsOrSDP(read: bytes, cands: List[AlignmentCandidate], anchors: List[list], params: MappingParameters, ctx,
+                           subreadLength: Optional[int] = None):
+    """AlignIntervals' choice of the guide (/root/reference/iblasr/BlasrAlignImpl.hpp:768-1004): when
+    the anchors of a candidate (its interval's exact matches, (q, t, l) in read / genome-window
+    coordinates) cover at least params.sdpBypassThreshold of the subread they are the guide
+    themselves (:992-1004: block = anchor - aligned-sequence position), otherwise the guide comes
+    from SDPAlign over the candidate's two sequences (:980-987).  The default threshold (1e6)
+    sends every candidate to SDPAlign.  The -rbao variant (SDP between consecutive anchors only,
+    :785-978) is not mirrored."""
+    n_sub = subreadLength if subreadLength is not None else len(read)
+    todo = []
+    for c, a in zip(cands, anchors):
+        covered = sum(int(m[2]) for m in a)
+        if n_sub and covered / n_sub >= params.sdpBypassThreshold:
+            b = np.zeros(len(a), dtype=BLOCK_DT)
+            for i, (q, t, l) in enumerate(a):
+                b[i] = (int(q) - c.qAlignedSeqPos, int(t) - c.tAlignedSeqPos, int(l))
+            c.blocks = b
+            c.status = _lib.PAIR_OK if len(b) else _lib.PAIR_EMPTY_GUIDE
+        else:
+            todo.append(c)
+    if todo:
+        SDPAlignCandidates(read, todo, params, ctx)
     return cands
 
 

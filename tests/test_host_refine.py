@@ -247,3 +247,14 @@ def test_cpp_guides_then_refine_matches_the_oracles(oracle, synth):
         assert v[:6] == [0, er["score"], er["ncells"], er["q_pos"], er["t_pos"], er["n_blk"]]
         got = np.array(v[6:]).reshape(-1, 3)
         assert np.array_equal(got[:, 0], eb["q_pos"]) and np.array_equal(got[:, 1], eb["t_pos"]) and np.array_equal(got[:, 2], eb["length"])
+
+
+def test_dense_anchors_bypass_the_guide_producer():
+    """AlignIntervals' shortcut: anchors that cover enough of the read are the guide (no device call)."""
+    from blasr_amd import refine
+    read = b"ACGT" * 50
+    c = refine.AlignmentCandidate(tAlignedSeq=b"ACGT" * 60, tAlignedSeqPos=1000, qAlignedSeqPos=10)
+    anchors = [[(10, 1000, 80), (100, 1095, 90)]]
+    params = refine.MappingParameters(sdpBypassThreshold=0.75)
+    refine.GuidesFromAnchorsOrSDP(read, [c], anchors, params, ctx=None)
+    assert [tuple(int(v) for v in b) for b in c.blocks] == [(0, 0, 80), (90, 95, 90)] and c.status == 0
