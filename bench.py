@@ -336,6 +336,19 @@ def main():
                                "host_cpus_visible": len(os.sched_getaffinity(0)),
                                "sample": "%d pairs of the same batch in %.1f s (oracle: C restatement built -O3 -march=x86-64-v3, "
                                          "one thread per core with private work space; not the BLASR binary)" % (done, secs)}
+        if "guide_production" in out:
+            # the guide producer's CPU restatement on the same cores, a few seconds of the same batch
+            from concurrent.futures import ThreadPoolExecutor
+            from oracle import oracle as _o
+            op = _o.make_sdp_params(k=sp.tuple_size, ins=sp.ins, dele=sp.dele, match=sp.match, max_fragments=sp.max_fragments)
+            chunk, done, t1 = 8, 0, time.perf_counter()
+            with ThreadPoolExecutor(threads) as pool:
+                while time.perf_counter() - t1 < 4.0 and done + chunk * threads <= n:
+                    list(pool.map(lambda f: _o.sdp_chain_batch(host, op, f, chunk), range(done, done + chunk * threads, chunk)))
+                    done += chunk * threads
+            secs = time.perf_counter() - t1
+            out["guide_production"]["cpu_baseline"] = {"pairs_per_sec": round(done / secs, 1), "cores": threads, "kind": "port",
+                                                       "sample": "%d pairs in %.1f s (oracle/sdp_oracle.c, one pair per call, %d threads)" % (done, secs, threads)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

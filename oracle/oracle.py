@@ -243,17 +243,18 @@ def sdp_chain_batch(batch, params, first=0, count=None):
     (status, n_blk, chain_score, n_frag, list of block arrays)."""
     n = int(batch["n_pairs"])
     count = n - first if count is None else count
-    caps = np.full(n, params.max_fragments, dtype=np.uint32)
-    out_off = np.arange(n, dtype=np.uint64) * np.uint64(params.max_fragments)
-    out = np.zeros(n * int(params.max_fragments), dtype=BLOCK_DT)
-    status = np.zeros(n, np.int32); n_blk = np.zeros(n, np.uint32); score = np.zeros(n, np.int32); n_frag = np.zeros(n, np.uint32)
-    arrs = {k: np.ascontiguousarray(batch[k]) for k in ("q_arena", "q_off", "t_arena", "t_off")}
-    q_len = np.ascontiguousarray(batch["q_len"], dtype=np.uint32)
-    t_len = np.ascontiguousarray(batch["t_len"], dtype=np.uint32)
+    sl = slice(first, first + count)
+    mf = int(params.max_fragments)
+    caps = np.full(count, mf, dtype=np.uint32)
+    out_off = np.arange(count, dtype=np.uint64) * np.uint64(mf)
+    out = np.zeros(max(count * mf, 1), dtype=BLOCK_DT)
+    status = np.zeros(count, np.int32); n_blk = np.zeros(count, np.uint32); score = np.zeros(count, np.int32); n_frag = np.zeros(count, np.uint32)
+    q_arena = np.ascontiguousarray(batch["q_arena"]); t_arena = np.ascontiguousarray(batch["t_arena"])
+    q_off = np.ascontiguousarray(np.asarray(batch["q_off"], dtype=np.uint64)[sl]); t_off = np.ascontiguousarray(np.asarray(batch["t_off"], dtype=np.uint64)[sl])
+    q_len = np.ascontiguousarray(np.asarray(batch["q_len"], dtype=np.uint32)[sl]); t_len = np.ascontiguousarray(np.asarray(batch["t_len"], dtype=np.uint32)[sl])
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    lib().sdo_chain_batch(p(arrs["q_arena"]), p(arrs["q_off"]), p(q_len), p(arrs["t_arena"]), p(arrs["t_off"]), p(t_len),
-                          C.byref(params), C.c_uint32(first), C.c_uint32(count),
+    lib().sdo_chain_batch(p(q_arena), p(q_off), p(q_len), p(t_arena), p(t_off), p(t_len),
+                          C.byref(params), C.c_uint32(0), C.c_uint32(count),
                           p(status), p(n_blk), p(score), p(n_frag), p(out), p(out_off), p(caps))
-    blks = [out[int(out_off[i]):int(out_off[i]) + int(n_blk[i])].copy() for i in range(first, first + count)]
-    s = slice(first, first + count)
-    return status[s].copy(), n_blk[s].copy(), score[s].copy(), n_frag[s].copy(), blks
+    blks = [out[i * mf:i * mf + int(n_blk[i])].copy() for i in range(count)]
+    return status, n_blk, score, n_frag, blks
