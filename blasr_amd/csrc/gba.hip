@@ -1697,33 +1697,32 @@ struct SdpConst {
     uint32_t stop;                // experiments: leave the kernel after this phase (0: run it all)
 };
 
-// query codes (code + 1, 6 for letters outside ACGT) of the whole read, 32 pad bytes behind it
-__global__ __launch_bounds__(256) void k_pack_q(Dev d, uint8_t *qcodes)
+// What k_sdp_match needs of a batch besides its constants (all device pointers).
+struct SdpIn {
+    const uint8_t *q_arena, *t_arena, *t_rc;
+    uint64_t q_arena_bytes, t_arena_bytes;
+    const uint64_t *q_off, *t_off;
+    const uint32_t *q_len, *t_len;
+};
+
+// status of a pair before any matching: slices inside their arenas, lengths the kernels can take
+__device__ __forceinline__ int sdp_pair_status(const SdpIn &in, uint32_t p, uint32_t k)
 {
-    const uint32_t p = blockIdx.x;
-    if (d.status[p] != GBA_PAIR_OK) return;
-    const uint32_t Q = d.Q[p];
-    const uint8_t *q = d.q_arena + d.q_off[p] + d.qS[p];
-    uint8_t *qc = qcodes + align16(d.row_off[p] + 48ull * p);
-    for (uint32_t x0 = 4 * threadIdx.x; x0 < Q + 32; x0 += 4 * blockDim.x) {
-        uint32_t w = 0;
-#pragma unroll
-        for (int x = 0; x < 4; x++) {
-            uint32_t c = 6u;
-            if (x0 + x < Q) { c = base_code(q[x0 + x]) + 1u; if (c == 5u) c = 6u; }
-            w |= c << (8 * x);
-        }
-        *(uint32_t *)(qc + x0) = w;
-    }
+    const uint64_t qo = in.q_off[p], to = in.t_off[p];
+    const uint32_t ql = in.q_len[p], tl = in.t_len[p];
+    if (to > in.t_arena_bytes || tl > in.t_arena_bytes - to || qo > in.q_arena_bytes || ql > in.q_arena_bytes - qo) return GBA_PAIR_BAD_GUIDE;
+    if (ql > 65535u || tl > 65535u) return GBA_PAIR_TOO_LONG;
+    if (ql < k || tl < k) return GBA_PAIR_EMPTY_GUIDE;
+    return GBA_PAIR_OK;
 }
 
-// largest query / target length of the pairs that are still OK (into two spare words of the plan)
-__global__ void k_sdp_max(Dev d)
+// longest read and longest window among the pairs that will be matched (mx[0], mx[1]: zeroed by the caller)
+__global__ void k_sdp_max(SdpIn in, uint32_t n, uint32_t k, uint32_t *mx)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= d.n || d.status[p] != GBA_PAIR_OK) return;
-    atomicMax(&d.plan->cls_count[0], d.Q[p]);
-    atomicMax(&d.plan->cls_count[1], d.T[p]);
+    if (p >= n || sdp_pair_status(in, p, k) != GBA_PAIR_OK) return;
+    atomicMax(&mx[0], in.q_len[p]);
+    atomicMax(&mx[1], in.t_len[p]);
 }
 
 // 16 bases (32 bits) of a packed array starting at base `pos`
@@ -1736,8 +1735,7 @@ __device__ __forceinline__ uint32_t window16(const uint32_t *pk, uint32_t pos)
 
 // Matches of one pair: its fragments (query start << 16 | target start, length) go to frags + pair * cap in no
 // particular order, their number to nfrag (above max_fragments: too many), the pair's status to out_status.
-__global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(Dev d, SdpConst sc, const uint8_t *qcodes, int32_t *out_status,
-                                                             uint2 *frags, uint32_t *nfrag)
+__global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(SdpIn in, SdpConst sc, int32_t *out_status, uint2 *frags, uint32_t *nfrag)
 {
     extern __shared__ uint32_t smem[];
     __shared__ uint32_t s_nfrag, s_hits, s_nq;
@@ -1752,31 +1750,40 @@ __global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(Dev d, SdpConst sc, c
     uint32_t *hq = smem + SLOTS + sc.tile / 2;                            // queue of hits: query position << 16 | list head
     uint32_t *qp = hq + sc.queue, *qs = qp + sc.qwords, *tp = qs + sc.qwords, *ts = tp + sc.twords;
 
-    int st = d.status[p];
-    const uint32_t Q = d.Q[p], T = d.T[p];
-    if (st == GBA_PAIR_OK && T > 65535u) st = GBA_PAIR_TOO_LONG;          // (the query is limited to 65 535 bases by k_meta)
-    if (st == GBA_PAIR_OK && (Q < sc.k || T < sc.k)) st = GBA_PAIR_EMPTY_GUIDE;
+    const int st = sdp_pair_status(in, p, sc.k);
     if (st != GBA_PAIR_OK) {                                              // uniform over the workgroup
         if (tid == 0) { out_status[p] = st; nfrag[p] = 0; }
         return;
     }
+    const uint32_t Q = in.q_len[p], T = in.t_len[p];
     if (tid == 0) { s_nfrag = 0; s_hits = 0; }
-    // ---- pack both sequences: 16 bases per dword, and a dword of marks (01 per base that is no ACGT base of the sequence)
+    // ---- pack both sequences straight from the caller's letters: 16 bases per dword, and a dword of marks (01 per base
+    // that is no ACGT base of the sequence).  A window on the reverse strand is read backwards and complemented.
     {
-        const uint8_t *qc = qcodes + align16(d.row_off[p] + 48ull * p);
-        const uint8_t *tc = d.tcodes + tc_offset(d, p) + 1;
+        const uint8_t *qa = in.q_arena + in.q_off[p], *ta = in.t_arena + in.t_off[p];
+        const bool rc = in.t_rc != nullptr && in.t_rc[p] != 0;
         for (uint32_t w = tid; w < sc.qwords + sc.twords; w += SDP_THREADS) {
             const bool isq = w < sc.qwords;
             const uint32_t ww = isq ? w : w - sc.qwords, len = isq ? Q : T;
+            const uint8_t *seq = isq ? qa : ta;
+            const bool back = !isq && rc;
             uint32_t bases = 0, marks = 0x55555555u;
             if (ww * 16u < len) {
-                const u32x4u1 raw = *(const u32x4u1 *)((isq ? qc : tc) + 16u * ww);
                 marks = 0;
+                const uint32_t x0 = ww * 16u;
+                u32x4u1 raw = {0u, 0u, 0u, 0u};
+                const bool whole = x0 + 16u <= len;
+                // base x0 + x is byte x0 + x of the slice, or, read backwards, byte len - 1 - x0 - x
+                if (whole) raw = *(const u32x4u1 *)(seq + (back ? len - x0 - 16u : x0));
 #pragma unroll
                 for (int x = 0; x < 16; x++) {
-                    const uint32_t c = (raw[x >> 2] >> (8 * (x & 3))) & 0xffu;      // code + 1: 1..4, above that no base
-                    const bool ok = c <= 4u && ww * 16u + (uint32_t)x < len;
-                    bases |= (ok ? c - 1u : 0u) << (2 * x);
+                    uint32_t letter;
+                    if (whole) { const int y = back ? 15 - x : x; letter = (raw[y >> 2] >> (8 * (y & 3))) & 0xffu; }
+                    else letter = x0 + (uint32_t)x < len ? seq[back ? len - 1u - x0 - (uint32_t)x : x0 + (uint32_t)x] : (uint32_t)'N';
+                    uint32_t code = base_code((uint8_t)letter);
+                    const bool ok = code < 4u;
+                    if (back) code = 3u - code;
+                    bases |= (ok ? code : 0u) << (2 * x);
                     marks |= (ok ? 0u : 1u) << (2 * x);
                 }
             }
@@ -2598,10 +2605,8 @@ int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides
     Slot &sl = c->slot[0];
     hipStream_t s = sl.s;
     const uint32_t per = n < SDP_PART ? n : SDP_PART;
-    for (int i = 0; i < 14; i++) { int rc = ensure(c, c->b_pair32[i], (size_t)per * 4); if (rc) return rc; }
-    for (int i = 0; i < 5; i++) { int rc = ensure(c, c->b_pair64[i], (size_t)per * 8); if (rc) return rc; }
+    { int rc = ensure(c, c->b_pair32[0], (size_t)per * 4); if (rc) return rc; }
     { int rc = ensure(c, c->b_needed, 16); if (rc) return rc; }
-    { int rc = ensure(c, sl.b_plan, sizeof(Plan)); if (rc) return rc; }
     uint64_t *needed = (uint64_t *)c->b_needed.ptr;
     HIPCHK(c, hipMemsetAsync(needed, 0, 16, s));
     SdpConst k;
@@ -2617,60 +2622,40 @@ int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides
         HIPCHK(c, hipFuncSetAttribute((const void *)k_sdp_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         c->sdp_attr_set = true;
     }
+    SdpIn in;
+    in.q_arena = b->q_arena; in.t_arena = b->t_arena; in.t_rc = b->t_rc;
+    in.q_arena_bytes = b->q_arena_bytes; in.t_arena_bytes = b->t_arena_bytes;
+    if (!in.t_arena) { in.t_arena = (const uint8_t *)c->b_ref.ptr; in.t_arena_bytes = c->ref_len; }
+    in.q_off = b->q_off; in.t_off = b->t_off; in.q_len = b->q_len; in.t_len = b->t_len;
+    // the one thing the host must know of the batch: its longest read and window (they size the kernel's LDS)
+    hipLaunchKernelGGL(k_sdp_max, dim3((n + 255) / 256), dim3(256), 0, s, in, n, k.k, (uint32_t *)(needed + 1));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_needed + 1, needed + 1, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const uint32_t maxQ = ((const uint32_t *)(c->h_needed + 1))[0], maxT = ((const uint32_t *)(c->h_needed + 1))[1];
+    // the target is indexed a tile at a time: tile positions x slots per position, sized to the longest window
+    k.tile = 256; while (k.tile < maxT && k.tile < c->sdp_tile_max) k.tile <<= 1;
+    k.slots_log2 = 1; while ((1u << k.slots_log2) < c->sdp_slots_per_pos * k.tile) k.slots_log2++;
+    while (k.slots_log2 > 2u * k.k) k.slots_log2--;                 // short tuples: no more slots than k-mers exist
+    k.qwords = maxQ / 16 + 3; k.twords = maxT / 16 + 3;
+    size_t lds;
+    k.queue = c->sdp_queue;
+    for (;;) {
+        lds = ((size_t)(1u << k.slots_log2) + k.tile / 2 + k.queue + 2 * (size_t)(k.qwords + k.twords)) * 4;
+        if (lds <= 160 * 1024 - 256 || k.tile <= 256) break;
+        k.tile >>= 1; k.slots_log2--;                                   // long sequences leave less room for the table
+    }
+    if (lds > 160 * 1024 - 256) return GBA_E_UNSUPPORTED;
+    { int rc = ensure(c, sl.b_blk, (size_t)per * k.max_fragments * sizeof(gba_block) + 16); if (rc) return rc; }
+    { int rc = ensure(c, sl.b_guide, (size_t)per * k.cap * sizeof(uint2) + 16); if (rc) return rc; }
+    uint32_t *nfrag = (uint32_t *)c->b_pair32[0].ptr;
+    // the parts follow each other on the stream without the host in between; they share the scratch
     for (uint32_t first = 0; first < n; first += per) {
         const uint32_t cnt = n - first < per ? n - first : per;
-        Dev d;
-        memset(&d, 0, sizeof(d));
-        d.n = cnt;
-        d.q_arena = b->q_arena; d.t_arena = b->t_arena; d.t_rc = b->t_rc ? b->t_rc + first : nullptr;
-        d.q_arena_bytes = b->q_arena_bytes; d.t_arena_bytes = b->t_arena_bytes;
-        if (!d.t_arena) { d.t_arena = (const uint8_t *)c->b_ref.ptr; d.t_arena_bytes = c->ref_len; }
-        d.q_off = b->q_off + first; d.t_off = b->t_off + first; d.q_len = b->q_len + first; d.t_len = b->t_len + first;
-        d.status = (int32_t *)c->b_pair32[0].ptr;
-        d.qS = (uint32_t *)c->b_pair32[1].ptr; d.tS = (uint32_t *)c->b_pair32[2].ptr;
-        d.Q = (uint32_t *)c->b_pair32[3].ptr; d.T = (uint32_t *)c->b_pair32[4].ptr;
-        d.rows = (uint32_t *)c->b_pair32[5].ptr; d.cols = (uint32_t *)c->b_pair32[6].ptr;
-        d.span = (uint32_t *)c->b_pair32[7].ptr; d.lo_last = (uint32_t *)c->b_pair32[8].ptr;
-        d.cls = (uint32_t *)c->b_pair32[9].ptr; d.order = (uint32_t *)c->b_pair32[10].ptr;
-        d.dp_score = (int32_t *)c->b_pair32[11].ptr; d.wcap = (uint32_t *)c->b_pair32[12].ptr; d.recdw = (uint32_t *)c->b_pair32[13].ptr;
-        d.row_off = (uint64_t *)c->b_pair64[0].ptr; d.col_off = (uint64_t *)c->b_pair64[1].ptr;
-        d.rec_off = (uint64_t *)c->b_pair64[2].ptr; d.ncells = (uint64_t *)c->b_pair64[3].ptr;
-        d.word_off = (uint64_t *)c->b_pair64[4].ptr;
-        d.plan = (Plan *)sl.b_plan.ptr;
-        // the whole read against the whole window: the k-band mode of k_meta with no limit on the length difference
-        HIPCHK(c, hipMemsetAsync(d.plan, 0, sizeof(Plan), s));
-        hipLaunchKernelGGL(k_meta, dim3((cnt + 255) / 256), dim3(256), 0, s, d, (int)GBA_MODE_KBAND, 0x7fffffff, 0u, 0u, 0xffffffffu);
-        hipLaunchKernelGGL(k_scan3, dim3(1), dim3(SCAN_T), 0, s, d);
-        hipLaunchKernelGGL(k_sdp_max, dim3((cnt + 255) / 256), dim3(256), 0, s, d);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(sl.h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        const uint64_t rows = sl.h_plan->total_rows, cols = sl.h_plan->total_cols;
-        const uint32_t maxQ = sl.h_plan->cls_count[0], maxT = sl.h_plan->cls_count[1] > 65535u ? 65535u : sl.h_plan->cls_count[1];
-        { int rc = ensure(c, sl.b_tc, (size_t)(cols + 48ull * cnt + 64 + 2 * ARENA_SLACK)); if (rc) return rc; }
-        { int rc = ensure(c, sl.b_rec, (size_t)(rows + 48ull * cnt + 64)); if (rc) return rc; }
-        { int rc = ensure(c, sl.b_blk, (size_t)cnt * k.max_fragments * sizeof(gba_block) + 16); if (rc) return rc; }
-        d.tcodes = (uint8_t *)sl.b_tc.ptr + ARENA_SLACK;
-        uint8_t *qcodes = (uint8_t *)sl.b_rec.ptr;
-        hipLaunchKernelGGL(k_pack, dim3(cnt), dim3(256), 0, s, d);
-        hipLaunchKernelGGL(k_pack_q, dim3(cnt), dim3(256), 0, s, d, qcodes);
-        // the target is indexed a tile at a time: a tile of half the hash slots, sized to the longest window (up to SDP_TILE_MAX)
-        k.tile = 256; while (k.tile < maxT && k.tile < c->sdp_tile_max) k.tile <<= 1;
-        k.slots_log2 = 1; while ((1u << k.slots_log2) < c->sdp_slots_per_pos * k.tile) k.slots_log2++;
-        while (k.slots_log2 > 2u * k.k) k.slots_log2--;                 // short tuples: no more slots than k-mers exist
-        k.qwords = maxQ / 16 + 3; k.twords = maxT / 16 + 3;
-        size_t lds;
-        k.queue = c->sdp_queue;
-        for (;;) {
-            lds = ((size_t)(1u << k.slots_log2) + k.tile / 2 + k.queue + 2 * (size_t)(k.qwords + k.twords)) * 4;
-            if (lds <= 160 * 1024 - 256 || k.tile <= 256) break;
-            k.tile >>= 1; k.slots_log2--;                                   // long sequences leave less room for the table
-        }
-        if (lds > 160 * 1024 - 256) return GBA_E_UNSUPPORTED;
-        { int rc = ensure(c, sl.b_guide, (size_t)cnt * k.cap * sizeof(uint2) + 16); if (rc) return rc; }
-        uint32_t *nfrag = d.span;                  // a spare per-pair array
-        hipLaunchKernelGGL(k_sdp_match, dim3(cnt), dim3(SDP_THREADS), lds, s, d, k, (const uint8_t *)qcodes, out->status + first,
-                           (uint2 *)sl.b_guide.ptr, nfrag);
+        SdpIn pin = in;
+        pin.q_off += first; pin.t_off += first; pin.q_len += first; pin.t_len += first;
+        if (pin.t_rc) pin.t_rc += first;
+        hipLaunchKernelGGL(k_sdp_match, dim3(cnt), dim3(SDP_THREADS), lds, s, pin, k, out->status + first, (uint2 *)sl.b_guide.ptr, nfrag);
         {
             const uint32_t small = k.cap < SDP_SMALL ? k.cap : SDP_SMALL;
             hipLaunchKernelGGL(k_sdp_chain, dim3(cnt), dim3(64), (size_t)small * 16 + 16, s, k, (const uint2 *)sl.b_guide.ptr, (const uint32_t *)nfrag,
