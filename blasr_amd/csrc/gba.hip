@@ -1904,27 +1904,60 @@ __global__ __launch_bounds__(64) void k_sdp_chain(SdpConst sc, const uint2 *frag
         return;
     }
     if (n <= n_above || n > n_upto) return;
-    uint32_t P2 = 1;
-    while (P2 < n) P2 <<= 1;
-    {
-        const uint2 *src = frags + (uint64_t)p * sc.cap;
+    // ---- sort by (query start, target start); the keys are distinct
+    const uint2 *src = frags + (uint64_t)p * sc.cap;
+    if (n <= SDP_SMALL) {
+        // by rank: a lane keeps its (at most 8) fragments in registers, counts for each the keys below it with uniform LDS
+        // reads of all keys, and puts it at that place: a third of the instructions of the bitonic network at ~300 fragments
+        constexpr int OWN = SDP_SMALL / 64;
+        uint2 own[OWN];
+        uint32_t rank[OWN];
+#pragma unroll
+        for (int z = 0; z < OWN; z++) {
+            const uint32_t i = tid + 64u * (uint32_t)z;
+            own[z] = i < n ? src[i] : make_uint2(0xffffffffu, 0u);
+            rank[z] = 0;
+            if (i < n) F[i].x = own[z].x;
+        }
+        __syncthreads();
+        const uint32_t n8 = (n + 7u) & ~7u;                   // (the keys behind the last fragment: set below, never smaller than a key)
+        for (uint32_t i = n + tid; i < n8; i += 64) F[i].x = 0xffffffffu;
+        __syncthreads();
+        for (uint32_t q0 = 0; q0 < n8; q0 += 8) {
+            uint32_t key[8];
+#pragma unroll
+            for (int y = 0; y < 8; y++) key[y] = F[q0 + y].x;
+#pragma unroll
+            for (int z = 0; z < OWN; z++)
+#pragma unroll
+                for (int y = 0; y < 8; y++) rank[z] += key[y] < own[z].x ? 1u : 0u;
+        }
+        __syncthreads();
+        if (sc.stop == 2) return;
+#pragma unroll
+        for (int z = 0; z < OWN; z++)
+            if (tid + 64u * (uint32_t)z < n) F[rank[z]] = make_uint4(own[z].x, own[z].y, 0u, 0xffffu);
+        __syncthreads();
+    } else {
+        uint32_t P2 = 1;
+        while (P2 < n) P2 <<= 1;
         for (uint32_t i = tid; i < P2; i += 64) {
             const uint2 f = i < n ? src[i] : make_uint2(0xffffffffu, 0u);
             F[i] = make_uint4(f.x, f.y, 0u, 0xffffu);
         }
-    }
-    __syncthreads();
-    if (sc.stop == 2) return;
-    // ---- sort by (query start, target start): bitonic, one compare-exchange per lane and step
-    for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1)
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            for (uint32_t e = tid; e < P2 / 2; e += 64) {
-                const uint32_t i = ((e & ~(j - 1u)) << 1) | (e & (j - 1u)), o = i | j;       // the pair (i, i + j) number e
-                const uint4 a = F[i], b = F[o];
-                if ((a.x > b.x) == ((i & k2) == 0u)) { F[i] = b; F[o] = a; }
+        __syncthreads();
+        if (sc.stop == 2) return;
+        // bitonic, one compare-exchange per lane and step
+        for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1)
+            for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+                for (uint32_t e = tid; e < P2 / 2; e += 64) {
+                    const uint32_t i = ((e & ~(j - 1u)) << 1) | (e & (j - 1u)), o = i | j;       // the pair (i, i + j) number e
+                    const uint4 a = F[i], b = F[o];
+                    if ((a.x > b.x) == ((i & k2) == 0u)) { F[i] = b; F[o] = a; }
+                }
+                __syncthreads();
             }
-            __syncthreads();
-        }
+    }
     if (sc.stop == 3) return;
     // ---- chain
     const int32_t M = sc.match, INS = sc.ins, DEL = sc.del;
