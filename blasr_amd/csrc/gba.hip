@@ -1769,22 +1769,34 @@ __global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(SdpIn in, SdpConst sc
             const bool back = !isq && rc;
             uint32_t bases = 0, marks = 0x55555555u;
             if (ww * 16u < len) {
-                marks = 0;
                 const uint32_t x0 = ww * 16u;
-                u32x4u1 raw = {0u, 0u, 0u, 0u};
-                const bool whole = x0 + 16u <= len;
+                u32x4u1 raw = {0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu};     // 'N'
                 // base x0 + x is byte x0 + x of the slice, or, read backwards, byte len - 1 - x0 - x
-                if (whole) raw = *(const u32x4u1 *)(seq + (back ? len - x0 - 16u : x0));
+                if (x0 + 16u <= len) {
+                    raw = *(const u32x4u1 *)(seq + (back ? len - x0 - 16u : x0));
+                    if (back) {                      // last byte first
+                        const u32x4u1 r = raw;
+                        raw[0] = __builtin_bswap32(r[3]); raw[1] = __builtin_bswap32(r[2]); raw[2] = __builtin_bswap32(r[1]); raw[3] = __builtin_bswap32(r[0]);
+                    }
+                } else {
+                    for (uint32_t x = 0; x0 + x < len; x++)
+                        raw[x >> 2] = (raw[x >> 2] & ~(0xffu << (8 * (x & 3)))) | (uint32_t)seq[back ? len - 1u - x0 - x : x0 + x] << (8 * (x & 3));
+                }
+                bases = 0; marks = 0;
 #pragma unroll
-                for (int x = 0; x < 16; x++) {
-                    uint32_t letter;
-                    if (whole) { const int y = back ? 15 - x : x; letter = (raw[y >> 2] >> (8 * (y & 3))) & 0xffu; }
-                    else letter = x0 + (uint32_t)x < len ? seq[back ? len - 1u - x0 - (uint32_t)x : x0 + (uint32_t)x] : (uint32_t)'N';
-                    uint32_t code = base_code((uint8_t)letter);
-                    const bool ok = code < 4u;
-                    if (back) code = 3u - code;
-                    bases |= (ok ? code : 0u) << (2 * x);
-                    marks |= (ok ? 0u : 1u) << (2 * x);
+                for (int z = 0; z < 4; z++) {
+                    // four letters at once: A 0x41, C 0x43, G 0x47, T 0x54 (case bit cleared) give code = bits 1..2 ^ bit 2,
+                    // and a letter is one of the four when the code's own letter is the letter
+                    const uint32_t u = raw[z] & 0xdfdfdfdfu;
+                    uint32_t code = ((u >> 1) & 0x03030303u) ^ ((u >> 2) & 0x01010101u);
+                    const uint32_t diff = __builtin_amdgcn_perm(0u, 0x54474341u, code) ^ u;                 // zero byte: a base
+                    const uint32_t bad = ((((diff & 0x7f7f7f7fu) + 0x7f7f7f7fu) | diff) & 0x80808080u) >> 7;   // bits 0, 8, 16, 24
+                    if (back) code ^= 0x03030303u;                                                             // complement
+                    code &= ~(bad * 3u);                                                                       // no base: 0, marked
+                    // the four 2-bit fields at bits 0, 8, 16, 24 side by side in one byte
+                    uint32_t c2 = code | code >> 6, m2 = bad | bad >> 6;
+                    c2 = (c2 | c2 >> 12) & 0xffu; m2 = (m2 | m2 >> 12) & 0x55u;
+                    bases |= c2 << (8 * z); marks |= m2 << (8 * z);
                 }
             }
             (isq ? qp : tp)[ww] = bases;
