@@ -106,9 +106,22 @@ def host_child(args):
         rc, needed = pipe.wait()
     dt = (time.perf_counter() - t0) / args.host_steps
     hb, pairs, blocks = bufs[(args.host_steps - 1) % args.host_contexts]
+    dig_full = results_digest(pairs, blocks[:needed])
+    # the same without a block arena (interval / summary output): only the pair results come back
+    for b in bufs:
+        b[1]["score"][:] = 0
+    t1 = time.perf_counter()
+    pipe.submit(bufs[0][0], bufs[0][1], None)
+    for i in range(args.host_steps):
+        if i + 1 < args.host_steps:
+            pipe.submit(bufs[(i + 1) % args.host_contexts][0], bufs[(i + 1) % args.host_contexts][1], None)
+        rc2, needed2 = pipe.wait()
+    dt_iv = (time.perf_counter() - t1) / args.host_steps
+    iv_same = rc2 == 0 and needed2 == needed and results_digest(pairs, blocks[:0])[:3] == dig_full[:3]
     h2d = sum(hb[x].nbytes for x in ("q_arena", "blocks", "q_off", "t_off", "blk_off", "q_len", "t_len", "n_blk", "t_rc"))
     print(json.dumps({"ms_per_step": dt * 1e3, "h2d_bytes": h2d, "d2h_bytes": n * _lib.PAIR_RESULT_DT.itemsize + needed * _lib.BLOCK_DT.itemsize,
-                      "cells": int(pairs["ncells"][pairs["status"] == 0].sum()), "digest": results_digest(pairs, blocks[:needed])}), flush=True)
+                      "cells": int(pairs["ncells"][pairs["status"] == 0].sum()), "digest": dig_full,
+                      "intervals_ms_per_step": dt_iv * 1e3, "intervals_ok": bool(iv_same)}), flush=True)
     pipe.close()
 
 
@@ -325,6 +338,11 @@ def main():
                                    "h2d_gb": round(h["h2d_bytes"] / 1e9, 3), "d2h_gb": round(h["d2h_bytes"] / 1e9, 3),
                                    "frac_of_device_resident": round(hg / gcups, 3),
                                    "same_results_as_device_path": h["digest"] == digest,
+                                   "intervals_only": {"gcups": round(h["cells"] / (h["intervals_ms_per_step"] / 1e3) / 1e9, 2),
+                                                      "ms_per_step": round(h["intervals_ms_per_step"], 3),
+                                                      "d2h_gb": round(n * 88 / 1e9, 3), "ok": h["intervals_ok"],
+                                                      "what": "the same batches with gba_results.blocks == NULL: pair results (score, counts, "
+                                                              "aligned interval) only, as interval (-m 4) output needs"},
                                    "how": "gba_submit / gba_wait, batch and results in page-locked memory (gba_host_alloc), targets = windows of "
                                           "the resident reference, %d contexts used in turn on the GPU, %d batches back to back, "
                                           "GPU_MAX_HW_QUEUES=16, child process on the system HIP runtime" % (args.host_contexts, args.host_steps)}

@@ -27,7 +27,8 @@ PAIR_RESULT_DT = np.dtype([
     ("status", "<i4"), ("dp_score", "<i4"), ("score", "<i4"),
     ("q_pos", "<u4"), ("t_pos", "<u4"), ("n_blk", "<u4"), ("blk_off", "<u8"),
     ("n_match", "<u4"), ("n_mismatch", "<u4"), ("n_ins", "<u4"), ("n_del", "<u4"),
-    ("rows", "<u4"), ("cols", "<u4"), ("ncells", "<u8"), ("extra_score", "<i4", (2,))], align=True)
+    ("rows", "<u4"), ("cols", "<u4"), ("ncells", "<u8"), ("extra_score", "<i4", (2,)),
+    ("q_start", "<u4"), ("q_end", "<u4"), ("t_start", "<u4"), ("t_end", "<u4")], align=True)
 
 
 class Config(C.Structure):

@@ -145,9 +145,12 @@ class Context:
     def submit_host(self, batch, pairs, blocks, cigar=None):
         """gba_submit: returns at once; `pairs` (ndarray[PAIR_RESULT_DT], one per pair) and `blocks`
         (ndarray[BLOCK_DT]) are filled while the batch runs and must not be read before
-        wait_host() has returned.  cigar: optional (ops ndarray[uint32], off ndarray[uint64] of
+        wait_host() has returned.  blocks None (or empty): the blocks are not wanted, only the pair
+        results (with the aligned interval) and the CIGARs travel.  cigar: optional (ops ndarray[uint32], off ndarray[uint64] of
         n_pairs + 1, flags) to receive the CIGAR operations as well."""
         b, keep = make_batch_struct(batch)
+        if blocks is None:
+            blocks = np.zeros(0, dtype=BLOCK_DT)
         r = Results(_ptr(pairs), _ptr(blocks) if len(blocks) else None, len(blocks), 0)
         if cigar is not None:
             ops, off, flags = cigar
@@ -176,6 +179,15 @@ class Context:
         self.submit_host(batch, pairs, blocks)
         rc, needed = self.wait_host()
         return pairs, blocks[:min(needed, int(blocks_capacity))], rc
+
+    def refine_host_intervals(self, batch):
+        """The interval (-m 4) form of refine_host: pair results only, each with score, the column
+        counts and the aligned interval q_start..q_end / t_start..t_end; no blocks are packed or
+        copied out.  Returns (pairs, rc)."""
+        pairs = np.zeros(int(batch["n_pairs"]), dtype=PAIR_RESULT_DT)
+        self.submit_host(batch, pairs, None)
+        rc, _ = self.wait_host()
+        return pairs, rc
 
     def refine_host_cigar(self, batch, flags=_lib.CIGAR_SEQ_MATCH, cigar_capacity=None, blocks_capacity=None):
         """refine_host that also returns the CIGAR operations: (pairs, blocks, ops, off, rc), the
@@ -249,7 +261,8 @@ class Context:
         """dbatch: dict of torch CUDA tensors with the same keys as a host batch (uint8 arenas;
         offsets/lengths as int64/int32 tensors holding the uint64/uint32 bit patterns; blocks as
         an int32 tensor [n_blocks, 3]).  out_pairs: uint8 tensor of n*PAIR_RESULT_DT.itemsize
-        bytes; out_blocks: int32 tensor [capacity, 3].  Returns (rc, blocks_needed).
+        bytes; out_blocks: int32 tensor [capacity, 3], or None when the blocks are not wanted (pair
+        results with the aligned interval only).  Returns (rc, blocks_needed).
         no_alloc: through gba_submit_device_noalloc (fixed scratch, no device allocation; a batch
         that does not fit raises GbaError with code E_TOOBIG).
         cigar: optional (ops int32 tensor [capacity], off int64 tensor [n + 1], flags); the total number
@@ -263,7 +276,8 @@ class Context:
                   dbatch["q_arena"].numel(), ta.numel() if ta is not None else 0, dbatch["blocks"].shape[0],
                   trc.data_ptr() if trc is not None else None)
         assert out_pairs.numel() * out_pairs.element_size() >= n * PAIR_RESULT_DT.itemsize
-        r = Results(out_pairs.data_ptr(), out_blocks.data_ptr(), out_blocks.shape[0], 0)
+        r = Results(out_pairs.data_ptr(), out_blocks.data_ptr() if out_blocks is not None else None,
+                    out_blocks.shape[0] if out_blocks is not None else 0, 0)
         if cigar is not None:
             ops, off, flags = cigar
             assert ops.element_size() == 4 and off.element_size() == 8 and off.numel() >= n + 1 and ops.numel() > 0

@@ -1491,28 +1491,36 @@ __global__ __launch_bounds__(SCAN_T) void k_scan1(Dev d, uint64_t *needed)
     if (threadIdx.x == 0) *needed = carry;
 }
 
-// One block per pair: completes the pair's result record and copies its blocks into the caller's
-// arena; pairs whose blocks do not fit get NOSPACE.
-__global__ __launch_bounds__(256) void k_emit(Dev d, gba_pair_result *res, gba_block *out, uint64_t capacity)
+// One block per pair: completes the pair's result record (the aligned interval included) and, when
+// the caller wants the blocks, copies them into the caller's arena; pairs whose blocks do not fit
+// get NOSPACE.
+__global__ __launch_bounds__(256) void k_emit(Dev d, gba_pair_result *res, gba_block *out, uint64_t capacity, int want_blocks)
 {
     const uint32_t p = blockIdx.x;
     const int st = d.status[p];
     const uint64_t off = d.word_off[p];
     const uint32_t nb = st == GBA_PAIR_OK ? d.span[p] : 0u;
-    const bool fits = off + nb <= capacity;
+    const bool fits = !want_blocks || off + nb <= capacity;
+    const gba_block *src = d.blk_scratch + d.row_off[p] + (d.Q[p] + 1 - nb);
     if (threadIdx.x == 0) {
         gba_pair_result &R = res[p];
         R.status = st;
         R.blk_off = off;
         if (st == GBA_PAIR_OK) {
             R.dp_score = d.dp_score[p];
-            R.q_pos = d.qS[p]; R.t_pos = d.tS[p];
+            const uint32_t qS = d.qS[p], tS = d.tS[p];
+            R.q_pos = qS; R.t_pos = tS;
             R.rows = d.Q[p]; R.cols = d.T[p]; R.ncells = d.ncells[p];
+            R.q_start = R.q_end = qS; R.t_start = R.t_end = tS;
+            if (nb) {
+                const gba_block a = src[0], z = src[nb - 1];
+                R.q_start = qS + a.q_pos; R.t_start = tS + a.t_pos;
+                R.q_end = qS + z.q_pos + z.length; R.t_end = tS + z.t_pos + z.length;
+            }
             if (!fits) R.status = GBA_PAIR_NOSPACE;
         }
     }
-    if (st != GBA_PAIR_OK || !fits) return;
-    const gba_block *src = d.blk_scratch + d.row_off[p] + (d.Q[p] + 1 - nb);
+    if (st != GBA_PAIR_OK || !fits || !want_blocks) return;
     gba_block *dst = out + off;
     for (uint32_t x = threadIdx.x; x < nb; x += blockDim.x) dst[x] = src[x];
 }
@@ -2455,22 +2463,24 @@ int finish_part(gba_ctx *c, HostIO &io, Slot &sl)
 {
     HIPCHK(c, hipEventSynchronize(sl.ev_cnt));
     const uint64_t after = sl.h_cnt[0], before = io.need_before, cnt = after - before;
+    const bool want = io.hout->blocks != nullptr;      // otherwise only the pair results (and CIGARs) travel
     const uint64_t cap = io.hout->blocks_capacity;
-    const uint64_t fit = before >= cap ? 0 : (after <= cap ? cnt : cap - before);     // blocks of this part the caller's arena takes
+    const uint64_t fit = !want || before >= cap ? 0 : (after <= cap ? cnt : cap - before);     // blocks of this part the caller's arena takes
     const bool cig = io.d_cigoff != nullptr;
     const uint64_t ops_after = cig ? sl.h_cnt[1] : 0, ops_before = io.ops_before, ops_cnt = ops_after - ops_before;
     const uint64_t ops_cap = io.hout->cigar_capacity;
     const uint64_t ops_fit = ops_before >= ops_cap ? 0 : (ops_after <= ops_cap ? ops_cnt : ops_cap - ops_before);
     if (sl.d2h_pending) {
         // the previous part of this slot may still be copying out of b_out / b_cig
-        if ((size_t)cnt * sizeof(gba_block) > sl.b_out.cap || (size_t)ops_cnt * 4 > sl.b_cig.cap) HIPCHK(c, hipEventSynchronize(sl.ev_d2h));
+        if ((want && (size_t)cnt * sizeof(gba_block) > sl.b_out.cap) || (size_t)ops_cnt * 4 > sl.b_cig.cap) HIPCHK(c, hipEventSynchronize(sl.ev_d2h));
         else HIPCHK(c, hipStreamWaitEvent(sl.s, sl.ev_d2h, 0));
     }
-    { int rc = ensure(c, sl.b_out, (size_t)cnt * sizeof(gba_block) + 16); if (rc) return rc; }
+    if (want) { int rc = ensure(c, sl.b_out, (size_t)cnt * sizeof(gba_block) + 16); if (rc) return rc; }
     if (cig) { int rc = ensure(c, sl.b_cig, (size_t)ops_cnt * 4 + 16); if (rc) return rc; }
     // offsets are those of the whole batch (that is what the caller's arena is indexed by), so the
     // part's buffer is addressed as if it began `before` blocks earlier
-    hipLaunchKernelGGL(k_emit, dim3(sl.dev.n), dim3(256), 0, sl.s, sl.dev, io.d_res + sl.first, (gba_block *)sl.b_out.ptr - before, cap);
+    hipLaunchKernelGGL(k_emit, dim3(sl.dev.n), dim3(256), 0, sl.s, sl.dev, io.d_res + sl.first,
+                       want ? (gba_block *)sl.b_out.ptr - before : (gba_block *)nullptr, cap, want ? 1 : 0);
     if (cig)
         hipLaunchKernelGGL(k_cigar<true>, dim3(sl.dev.n), dim3(64), 0, sl.s, sl.dev, io.hout->cigar_flags, io.d_cigoff + sl.first,
                            (uint32_t *)sl.b_cig.ptr - ops_before, ops_cap);
@@ -2480,7 +2490,7 @@ int finish_part(gba_ctx *c, HostIO &io, Slot &sl)
     HIPCHK(c, hipStreamWaitEvent(c->s_out, sl.ev_emit, 0));
     HIPCHK(c, hipMemcpyAsync(io.hout->pairs + sl.first, io.d_res + sl.first, (size_t)sl.dev.n * sizeof(gba_pair_result),
                              hipMemcpyDeviceToHost, c->s_out));
-    if (fit && io.hout->blocks)
+    if (fit)
         HIPCHK(c, hipMemcpyAsync(io.hout->blocks + before, sl.b_out.ptr, (size_t)fit * sizeof(gba_block), hipMemcpyDeviceToHost, c->s_out));
     if (cig) {
         // the entry one past the part is the next part's first (the same value) or the end of the batch
@@ -2510,6 +2520,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
     const uint32_t n = b->n_pairs;
     const bool cig = io ? io->d_cigoff != nullptr : out->cigar_ops != nullptr;
     uint64_t *cig_off = io ? io->d_cigoff : out->cigar_off;
+    const bool want_blocks = (io ? io->hout->blocks : out->blocks) != nullptr;
     out->blocks_needed = 0; out->cigar_needed = 0;
     HIPCHK(c, hipSetDevice(c->device));
     if (n == 0) {
@@ -2607,7 +2618,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
             if (h > 0) { rc = finish_part(c, *io, c->slot[(h - 1) % NSLOT]); if (rc) return rc; }
             continue;
         }
-        hipLaunchKernelGGL(k_emit, dim3(d.n), dim3(256), 0, sl.s, d, res + first, out->blocks, out->blocks_capacity);
+        hipLaunchKernelGGL(k_emit, dim3(d.n), dim3(256), 0, sl.s, d, res + first, out->blocks, out->blocks_capacity, want_blocks ? 1 : 0);
         if (cig)
             hipLaunchKernelGGL(k_cigar<true>, dim3(d.n), dim3(64), 0, sl.s, d, out->cigar_flags, (const uint64_t *)(cig_off + first),
                                out->cigar_ops, out->cigar_capacity);
@@ -2632,7 +2643,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
         t.fill_ms = acc.fill_sum; t.traceback_ms = acc.tb1 > acc.f1 ? acc.tb1 - acc.f1 : 0;
         HIPCHK(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[1]));
     }
-    return out->blocks_needed > out->blocks_capacity || out->cigar_needed > out->cigar_capacity ? GBA_E_NOSPACE : GBA_OK;
+    return (want_blocks && out->blocks_needed > out->blocks_capacity) || out->cigar_needed > out->cigar_capacity ? GBA_E_NOSPACE : GBA_OK;
 }
 
 // Guide production for a batch whose inputs and outputs are device pointers, in parts of at most
@@ -3063,7 +3074,7 @@ int gba_wait(gba_ctx *c)
     c->cv.wait(lk, [c] { return c->job_done; });
     c->in_flight = false;
     const int rc = c->job_rc;
-    if (rc == GBA_E_NOSPACE) {
+    if (rc == GBA_E_NOSPACE && c->job_out->blocks) {
         // pairs whose blocks lie beyond the caller's arena
         gba_results *out = c->job_out;
         for (uint32_t p = 0; p < c->job_batch.n_pairs; p++) {

@@ -101,8 +101,12 @@ def m4_line(cand, q_name: str, t_name: str, q_length: int, t_length: int, map_qv
             q_strand: int = 0) -> str:
     """One -m 4 record of a refined candidate (refine.AlignmentCandidate after RefineAlignments).
     Coordinates are those of the aligned strands; the caller passes names, full lengths and the
-    mapping quality, which are computed outside the refine stage."""
-    qs, qe, ts, te = aligned_interval(cand.blocks, cand.qAlignedSeqPos + cand.qPos, cand.tAlignedSeqPos + cand.tPos)
+    mapping quality, which are computed outside the refine stage.  A candidate refined without a
+    block arena (RefineAlignments(..., want_blocks=False)) carries its intervals from the pair result."""
+    if len(cand.blocks) == 0 and getattr(cand, "qInterval", None) is not None:
+        (qs, qe), (ts, te) = cand.qInterval, cand.tInterval
+    else:
+        qs, qe, ts, te = aligned_interval(cand.blocks, cand.qAlignedSeqPos + cand.qPos, cand.tAlignedSeqPos + cand.tPos)
     return "%s %s %d %g %d %d %d %d %d %d %d %d %d" % (
         q_name, t_name, cand.score, cand.pctSimilarity, q_strand, qs, qe, q_length,
         cand.tStrand, ts, te, t_length, map_qv)

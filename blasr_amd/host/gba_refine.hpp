@@ -50,6 +50,11 @@ struct AlignmentCandidate {
     int status = 0;
     float probScore = 0;           // the path under the probability scorer (StoreMapQVs, :135-151)
     int mapQV = 0, numSignificantClusters = 1;
+    // from the pair result: the aligned stretch of the read / of the window (GetQInterval, the -m 4 columns)
+    // and the number of blocks: what interval output and the mapping qualities need when a batch ran
+    // without a block arena (blocks is then empty)
+    uint32_t qStart = 0, qEnd = 0, tStart = 0, tEnd = 0, nBlocks = 0;
+    bool haveInterval = false;
 };
 
 // RefineAlignment never assigns affineOpen / affineExtend of its two DistanceMatrixScoreFunction
@@ -181,7 +186,9 @@ public:
     }
 
     // one submit/wait for everything added; copy-back of :733-772.  Returns the gba return code.
-    int Run(const MappingParameters &params)
+    // wantBlocks false: interval / summary output (printFormat Interval, SummaryPrint, :992-1000) prints only
+    // what the pair results hold, so no block is packed or copied out.
+    int Run(const MappingParameters &params, bool wantBlocks = true)
     {
         const uint32_t n = (uint32_t)cands_.size();
         if (n == 0) return GBA_OK;
@@ -198,9 +205,10 @@ public:
         b.q_arena_bytes = q_arena_.size(); b.t_arena_bytes = t_arena_.size(); b.n_blocks_total = blocks_.size();
         uint64_t cap = n;
         for (uint32_t l : q_len_) cap += l;
+        if (!wantBlocks) cap = 0;
         std::vector<gba_pair_result> pairs(n);
         std::vector<gba_block> out(cap);
-        gba_results r{pairs.data(), out.data(), cap, 0};
+        gba_results r{pairs.data(), wantBlocks ? out.data() : nullptr, cap, 0};
         if ((rc = gba_submit(ctx_, &b, &r)) != GBA_OK) return rc;     // returns at once: a caller with more reads
         if ((rc = gba_wait(ctx_)) != GBA_OK) return rc;               // to prepare does that here, before waiting
         for (uint32_t i = 0; i < n; i++) {
@@ -208,11 +216,12 @@ public:
             const gba_pair_result &p = pairs[i];
             c.status = p.status;
             if (p.status != GBA_PAIR_OK) continue;
-            c.blocks.resize(p.n_blk);
-            for (uint32_t k = 0; k < p.n_blk; k++) {
+            c.blocks.resize(wantBlocks ? p.n_blk : 0);
+            for (uint32_t k = 0; k < p.n_blk && wantBlocks; k++) {
                 const gba_block &g = out[p.blk_off + k];
                 c.blocks[k] = Block{g.q_pos, g.t_pos, g.length};
             }
+            c.nBlocks = p.n_blk;
             c.nMatch = p.n_match; c.nMismatch = p.n_mismatch; c.nIns = p.n_ins; c.nDel = p.n_del;
             const uint64_t cols = (uint64_t)p.n_match + p.n_mismatch + p.n_ins + p.n_del;
             c.pctSimilarity = cols ? (float)(p.n_match * 2.0 / (2.0 * cols) * 100.0) : 0.f;
@@ -222,6 +231,9 @@ public:
             c.tAlignedSeqPos += c.tPos; c.qAlignedSeqPos += c.qPos;
             c.tPos = p.t_pos; c.qPos = p.q_pos;
             c.tAlignedSeqLength = t_len_[i]; c.qAlignedSeqLength = q_len_[i];
+            c.qStart = c.qAlignedSeqPos + p.q_start; c.qEnd = c.qAlignedSeqPos + p.q_end;
+            c.tStart = c.tAlignedSeqPos + p.t_start; c.tEnd = c.tAlignedSeqPos + p.t_end;
+            c.haveInterval = true;
         }
         return GBA_OK;
     }
@@ -357,7 +369,7 @@ inline int RefineGlobal(const std::string &read, std::vector<AlignmentCandidate 
 
 // RefineAlignments for ONE read (:905-923): all its candidates in one batch, then the re-sort.
 inline int RefineAlignments(const std::string &read, std::vector<AlignmentCandidate *> &alignmentPtrs,
-                            const MappingParameters &params, gba_ctx *ctx)
+                            const MappingParameters &params, gba_ctx *ctx, bool wantBlocks = true)
 {
     if (!params.refineAlignments) return GBA_OK;
     int rc;
@@ -366,7 +378,7 @@ inline int RefineAlignments(const std::string &read, std::vector<AlignmentCandid
     else {
         RefineBatch batch(ctx);
         for (AlignmentCandidate *c : alignmentPtrs) batch.Add(read, c);
-        rc = batch.Run(params);
+        rc = batch.Run(params, wantBlocks);
     }
     if (rc == GBA_OK && params.sortRefinedAlignments)
         std::stable_sort(alignmentPtrs.begin(), alignmentPtrs.end(),
@@ -383,6 +395,7 @@ constexpr int kMaxPhredScore = 254, kMapQVEndAlignWiggle = 5;       // iblasr/Bl
 
 inline void GetQInterval(const AlignmentCandidate &c, int &start, int &end)
 {
+    if (c.blocks.empty() && c.haveInterval) { start = (int)c.qStart; end = (int)c.qEnd; return; }
     start = end = (int)(c.qAlignedSeqPos + c.qPos);
     if (c.blocks.empty()) return;
     end = start + (int)(c.blocks.back().qPos + c.blocks.back().length);

@@ -8,6 +8,7 @@
 //            for each candidate (what a parsing loop does)
 //   global   run the -global branch (RefineGlobal) on each (read, candidate) instead
 //   sdp      the guides come from the device first (SDPAlignCandidates: the blocks of the input are ignored), then the batch
+//   intervals  run without a block arena and print per candidate: status score nBlocks qStart qEnd tStart tEnd
 //   mapqv    no GPU: stdin is n, then "qStart qEnd rawProbScore" per candidate of ONE read; prints their mapQVs
 #include <cstdio>
 #include <iostream>
@@ -18,6 +19,7 @@ int main(int argc, char **argv)
 {
     const std::string mode = argc > 1 ? argv[1] : "";
     const bool cigar = mode == "cigar", reuse = mode == "reuse", global = mode == "global", sdp = mode == "sdp";
+    const bool intervals = mode == "intervals";
     size_t n;
     if (!(std::cin >> n)) return 2;
     if (mode == "mapqv") {
@@ -70,10 +72,17 @@ int main(int argc, char **argv)
             if (reuse) { buffer.assign(reads[i]); batch.Add(buffer, &cands[i]); }
             else batch.Add(reads[i], &cands[i]);
         }
-        rc = batch.Run(params);
+        rc = batch.Run(params, !intervals);
     }
     if (rc != GBA_OK) { std::fprintf(stderr, "Run: %s\n", gba_strerror(rc)); return 1; }
     for (auto &c : cands) {
+        if (intervals) {
+            int q0, q1;
+            gba::GetQInterval(c, q0, q1);
+            if ((uint32_t)q0 != c.qStart || (uint32_t)q1 != c.qEnd || !c.blocks.empty()) { std::fprintf(stderr, "interval mismatch\n"); return 1; }
+            std::printf("%d %d %u %u %u %u %u\n", c.status, c.score, c.nBlocks, c.qStart, c.qEnd, c.tStart, c.tEnd);
+            continue;
+        }
         std::printf("%d %d %llu %u %u %zu", c.status, c.score, (unsigned long long)c.nCells, c.qPos, c.tPos, c.blocks.size());
         for (auto &b : c.blocks) std::printf(" %u %u %u", b.qPos, b.tPos, b.length);
         if (cigar && c.status == 0)

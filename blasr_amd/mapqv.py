@@ -20,7 +20,10 @@ MAPQV_END_ALIGN_WIGGLE = 5       # iblasr/BlasrHeaders.h:20
 
 
 def q_interval(c):
-    """GetQInterval: [start, end) of the read the candidate aligns (all reads are forward)."""
+    """GetQInterval: [start, end) of the read the candidate aligns (all reads are forward).  A
+    candidate refined without a block arena carries the interval itself (from the pair result)."""
+    if len(c.blocks) == 0 and getattr(c, "qInterval", None) is not None:
+        return c.qInterval
     if len(c.blocks) == 0:
         s = c.qAlignedSeqPos + c.qPos
         return s, s

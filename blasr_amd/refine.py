@@ -69,6 +69,15 @@ class AlignmentCandidate:
     status: int = 0
     probScore: float = 0.0
     mapQV: int = 0
+    # filled by copy_back from the pair result: the aligned stretch of the read / of the target window
+    # (GetQInterval / the -m 4 columns) and the number of blocks, which are all an interval printer and
+    # the mapping qualities need when the blocks themselves were not asked for
+    qInterval: Optional[tuple] = None
+    tInterval: Optional[tuple] = None
+    nBlocks: int = 0
+
+    def n_blocks(self) -> int:
+        return max(len(self.blocks), self.nBlocks)
 
 
 # RefineAlignment never assigns affineOpen / affineExtend of its two DistanceMatrixScoreFunction
@@ -145,12 +154,17 @@ def build_batch(read: bytes, cands: List[AlignmentCandidate]):
 
 
 def copy_back(read: bytes, cands: List[AlignmentCandidate], batch, pairs, blocks):
-    """:733-772 for every candidate the kernels aligned."""
+    """:733-772 for every candidate the kernels aligned.  blocks None: the batch ran without a block
+    arena (interval output); the candidate then has no blocks, only their number and the intervals."""
     for i, (c, r) in enumerate(zip(cands, pairs)):
         c.status = int(r["status"])
         if c.status != _lib.PAIR_OK:
             continue
-        c.blocks = blocks[int(r["blk_off"]):int(r["blk_off"]) + int(r["n_blk"])].copy()
+        if blocks is None:
+            c.blocks = np.zeros(0, dtype=BLOCK_DT)
+        else:
+            c.blocks = blocks[int(r["blk_off"]):int(r["blk_off"]) + int(r["n_blk"])].copy()
+        c.nBlocks = int(r["n_blk"])
         c.nMatch, c.nMismatch = int(r["n_match"]), int(r["n_mismatch"])
         c.nIns, c.nDel = int(r["n_ins"]), int(r["n_del"])
         cols = c.nMatch + c.nMismatch + c.nIns + c.nDel
@@ -164,6 +178,8 @@ def copy_back(read: bytes, cands: List[AlignmentCandidate], batch, pairs, blocks
         c.qAlignedSeqPos += c.qPos
         c.tPos, c.qPos = int(r["t_pos"]), int(r["q_pos"])
         c.tAlignedSeqLength, c.qAlignedSeqLength = tl, ql
+        c.qInterval = (c.qAlignedSeqPos + int(r["q_start"]), c.qAlignedSeqPos + int(r["q_end"]))
+        c.tInterval = (c.tAlignedSeqPos + int(r["t_start"]), c.tAlignedSeqPos + int(r["t_end"]))
 
 
 def SDPAlignCandidates(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx):
@@ -245,8 +261,10 @@ def GuidedAlignFromSequences(read: bytes, cands: List[AlignmentCandidate], param
     return RefineAlignments(read, cands, p, ctx)
 
 
-def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx):
-    """Batched RefineAlignments (:905-923): all candidates of the read in one submit."""
+def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx, want_blocks: bool = True):
+    """Batched RefineAlignments (:905-923): all candidates of the read in one submit.
+    want_blocks False: for interval / summary output (printFormat Interval, SummaryPrint, :992-1000), which
+    prints only what the pair results hold: no block leaves the device."""
     if not params.refineAlignments or not cands:
         return cands
     if params.doGlobalAlignment:
@@ -258,7 +276,10 @@ def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: Mappi
         raise NotImplementedError("the legacy -noUseGuidedAlign branch (:775-902) is not on the accelerated path")
     ctx.set_scoring(scoring_from_params(params))
     batch = build_batch(read, cands)
-    pairs, blocks, rc = ctx.refine_host(batch)
+    if want_blocks:
+        pairs, blocks, rc = ctx.refine_host(batch)
+    else:
+        (pairs, rc), blocks = ctx.refine_host_intervals(batch), None
     copy_back(read, cands, batch, pairs, blocks)
     if params.sortRefinedAlignments:
         cands.sort(key=lambda c: c.score)        # stable, ascending: lower is better (:920-922)
@@ -321,7 +342,7 @@ def RemoveLowQualityAlignments(cands: List[AlignmentCandidate], params: MappingP
     """Drop from the first candidate that has no blocks or scores above maxScore
     (iblasr/BlasrUtilsImpl.hpp:485-509), as MapRead does right after refining."""
     for i, c in enumerate(cands):
-        if len(c.blocks) == 0 or c.score > params.maxScore:
+        if c.n_blocks() == 0 or c.score > params.maxScore:
             del cands[i:]
             break
     return cands

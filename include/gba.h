@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GBA_VERSION 320   /* major*10000 + minor*100 + patch */
+#define GBA_VERSION 330   /* major*10000 + minor*100 + patch */
 
 /* return codes of the entry points */
 enum {
@@ -146,6 +146,12 @@ typedef struct {
     uint32_t rows, cols;        /* query / target bases inside the DP region */
     uint64_t ncells;            /* refinedAlignment.nCells: sum over guide rows of tPre+tPost+1 */
     int32_t extra_score[GBA_MAX_EXTRA];   /* the path under gba_scoring.extra[] */
+    /* The aligned interval, first aligned base to one past the last, in q and in t as the aligner sees
+     * them: q_pos + first block's q_pos .. q_pos + last block's q_pos + length (what GetQInterval,
+     * iblasr/BlasrUtilsImpl.hpp:335, and the qStart qEnd tStart tEnd columns of -m 4 are made of,
+     * ctest/bug25328.t:12, ctest/hitpolicy.t:95).  With score, n_match .. n_del and the mapping
+     * quality this is the whole interval record, so a caller that prints intervals needs no blocks. */
+    uint32_t q_start, q_end, t_start, t_end;
 } gba_pair_result;
 
 /* CIGAR operations in the BAM encoding (length << 4 | op), the text-ready form of a refined
@@ -160,7 +166,9 @@ enum { GBA_CIGAR_M = 0, GBA_CIGAR_I = 1, GBA_CIGAR_D = 2, GBA_CIGAR_EQ = 7, GBA_
 
 typedef struct {
     gba_pair_result *pairs;     /* n_pairs entries */
-    gba_block *blocks;          /* arena for all pairs' blocks, relative to (q_pos, t_pos) */
+    gba_block *blocks;          /* arena for all pairs' blocks, relative to (q_pos, t_pos); NULL: blocks are not wanted (interval
+                                   and summary output, or CIGARs only): nothing is packed or copied out for them, no pair
+                                   gets GBA_PAIR_NOSPACE, blocks_capacity must be 0 and blocks_needed is still reported */
     uint64_t blocks_capacity;   /* in blocks */
     uint64_t blocks_needed;     /* out: total blocks of the batch */
     /* optional (cigar_ops == NULL: not wanted): the CIGAR of every aligned pair, packed in input order */
