@@ -201,6 +201,19 @@ def main():
             if len(kb) != len(ob) or not (np.array_equal(kb["q_pos"], ob["q_pos"]) and np.array_equal(kb["t_pos"], ob["t_pos"])
                                           and np.array_equal(kb["length"], ob["length"])):
                 bad = (p, "blocks", len(ob), len(kb)); break
+            qp, tp = int(k["q_pos"]), int(k["t_pos"])
+            want_iv = (qp, qp, tp, tp) if len(ob) == 0 else (
+                qp + int(ob[0]["q_pos"]), qp + int(ob[-1]["q_pos"]) + int(ob[-1]["length"]),
+                tp + int(ob[0]["t_pos"]), tp + int(ob[-1]["t_pos"]) + int(ob[-1]["length"]))
+            got_iv = tuple(int(k[f]) for f in ("q_start", "q_end", "t_start", "t_end"))
+            if got_iv != want_iv:
+                bad = (p, "interval", want_iv, got_iv); break
+        if not bad and rounds % 4 == 0:
+            # the same batch without a block arena: the same pair results, nothing refused for space
+            only, rc_iv = ctx.refine_host_intervals(batch)
+            if rc_iv != 0 or ctx.blocks_needed != len(blocks) or only.tobytes() != pairs.tobytes():
+                diff = [p for p in range(n) if only[p].tobytes() != pairs[p].tobytes()]
+                bad = (diff[0] if diff else 0, "no-arena run", rc_iv, len(diff))
         if not bad and cig is not None:
             bad = check_cigars(rng, emit, _lib, batch, pairs, blocks, cig[0], cig[1], cig[2])
             cigar_rounds += 1
