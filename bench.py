@@ -93,7 +93,7 @@ def host_child(args):
     pipe.set_reference(ref)
     bufs = []
     for _ in range(args.host_contexts):
-        bufs.append((pipe.pinned_copy(host), pipe.host_array(n, _lib.PAIR_RESULT_DT), pipe.host_array(args.host_blocks, _lib.BLOCK_DT)))
+        bufs.append((pipe.pinned_copy(host), pipe.host_array(n, _lib.PAIR_RESULT_DT), pipe.host_array(args.host_blocks + args.host_blocks // 12, _lib.BLOCK_DT)))
     for i in range(args.host_contexts):           # warm-up: every context once (its device buffers grow to size)
         pipe.submit(*bufs[i]); rc, needed = pipe.wait()
         if rc != 0:
@@ -119,8 +119,28 @@ def host_child(args):
     dt_iv = (time.perf_counter() - t1) / args.host_steps
     iv_same = rc2 == 0 and needed2 == needed and results_digest(pairs, blocks[:0])[:3] == dig_full[:3]
     h2d = sum(hb[x].nbytes for x in ("q_arena", "blocks", "q_off", "t_off", "blk_off", "q_len", "t_len", "n_blk", "t_rc"))
+    cells_guided = int(pairs["ncells"][pairs["status"] == 0].sum())
+    # from sequences alone: the batches without their guide blocks, the guides made on the device in the same call
+    pipe.set_guide_producer(api.make_sdp_params(max_fragments=1024 if cfg["read_len"] <= 25_000 else 4096))
+    seqs = [{k: v for k, v in b[0].items() if k not in ("blocks", "blk_off", "n_blk")} for b in bufs]
+    from_seq = {}
+    for what, want_blocks in (("blocks", True), ("intervals", False)):
+        for i in range(args.host_contexts):       # warm-up: the guide producer's scratch
+            pipe.submit(seqs[i], bufs[i][1], bufs[i][2] if want_blocks else None); rc3, needed3 = pipe.wait()
+        t2 = time.perf_counter()
+        pipe.submit(seqs[0], bufs[0][1], bufs[0][2] if want_blocks else None)
+        for i in range(args.host_steps):
+            if i + 1 < args.host_steps:
+                j = (i + 1) % args.host_contexts
+                pipe.submit(seqs[j], bufs[j][1], bufs[j][2] if want_blocks else None)
+            rc3, needed3 = pipe.wait()
+        ok3 = pairs["status"] == 0
+        from_seq[what] = {"ms_per_step": (time.perf_counter() - t2) / args.host_steps * 1e3, "rc": rc3, "pairs_ok": int(ok3.sum()),
+                          "cells": int(pairs["ncells"][ok3].sum()), "blocks_out": int(needed3),
+                          "score_per_base": float(pairs["score"][ok3].sum()) / max(1, int(pairs["rows"][ok3].sum()))}
+    h2d_seq = sum(seqs[0][x].nbytes for x in seqs[0] if x != "n_pairs")
     print(json.dumps({"ms_per_step": dt * 1e3, "h2d_bytes": h2d, "d2h_bytes": n * _lib.PAIR_RESULT_DT.itemsize + needed * _lib.BLOCK_DT.itemsize,
-                      "cells": int(pairs["ncells"][pairs["status"] == 0].sum()), "digest": dig_full,
+                      "cells": cells_guided, "digest": dig_full, "from_sequences": from_seq, "h2d_bytes_sequences": h2d_seq,
                       "intervals_ms_per_step": dt_iv * 1e3, "intervals_ok": bool(iv_same)}), flush=True)
     pipe.close()
 
@@ -343,6 +363,14 @@ def main():
                                                       "d2h_gb": round(n * 88 / 1e9, 3), "ok": h["intervals_ok"],
                                                       "what": "the same batches with gba_results.blocks == NULL: pair results (score, counts, "
                                                               "aligned interval) only, as interval (-m 4) output needs"},
+                                   "from_sequences": {
+                                       "what": "the same batches WITHOUT their guide blocks (gba_set_guide_producer): reads and windows in, guides made "
+                                               "on the device, refined alignments out; nothing of a guide crosses the link",
+                                       "h2d_gb": round(h["h2d_bytes_sequences"] / 1e9, 3),
+                                       **{k: {"ms_per_step": round(v["ms_per_step"], 3), "reads_per_sec": round(n / (v["ms_per_step"] / 1e3), 1),
+                                              "gcups": round(v["cells"] / (v["ms_per_step"] / 1e3) / 1e9, 2), "rc": v["rc"], "pairs_ok": v["pairs_ok"],
+                                              "blocks_out": v["blocks_out"], "score_per_base": round(v["score_per_base"], 4)}
+                                          for k, v in h["from_sequences"].items()}},
                                    "how": "gba_submit / gba_wait, batch and results in page-locked memory (gba_host_alloc), targets = windows of "
                                           "the resident reference, %d contexts used in turn on the GPU, %d batches back to back, "
                                           "GPU_MAX_HW_QUEUES=16, child process on the system HIP runtime" % (args.host_contexts, args.host_steps)}

@@ -92,7 +92,7 @@ class Guides(C.Structure):
 
 
 EXPORTS = ("gba_create", "gba_destroy", "gba_set_scoring", "gba_submit", "gba_wait",
-           "gba_submit_device", "gba_submit_device_noalloc", "gba_sdp_device", "gba_sdp", "gba_host_alloc", "gba_host_free", "gba_set_reference", "gba_get_timing", "gba_last_hip_error", "gba_strerror", "gba_version")
+           "gba_submit_device", "gba_submit_device_noalloc", "gba_sdp_device", "gba_sdp", "gba_set_guide_producer", "gba_host_alloc", "gba_host_free", "gba_set_reference", "gba_get_timing", "gba_last_hip_error", "gba_strerror", "gba_version")
 
 _lib = None
 
@@ -129,6 +129,7 @@ def lib():
         L.gba_submit_device_noalloc.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Results)]
         L.gba_sdp_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(SdpParams), C.POINTER(Guides)]
         L.gba_sdp.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(SdpParams), C.POINTER(Guides)]
+        L.gba_set_guide_producer.argtypes = [C.c_void_p, C.POINTER(SdpParams)]
         L.gba_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.gba_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         L.gba_last_hip_error.argtypes = [C.c_void_p]

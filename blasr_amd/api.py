@@ -65,10 +65,12 @@ def make_batch_struct(batch):
         ("q_len", np.uint32), ("t_len", np.uint32), ("n_blk", np.uint32), ("t_rc", np.uint8))
         if batch.get(k) is not None}
     ta = keep.get("t_arena")          # absent: windows of the reference given to set_reference
+    bl = keep.get("blocks")           # absent: the guides are made on the device (Context.set_guide_producer)
     b = Batch(n, _ptr(keep["q_arena"]), _ptr(keep["q_off"]), _ptr(keep["q_len"]),
               _ptr(ta) if ta is not None else None, _ptr(keep["t_off"]), _ptr(keep["t_len"]),
-              _ptr(keep["blocks"]), _ptr(keep["blk_off"]), _ptr(keep["n_blk"]),
-              keep["q_arena"].size, ta.size if ta is not None else 0, keep["blocks"].size,
+              _ptr(bl) if bl is not None else None, _ptr(keep["blk_off"]) if bl is not None else None,
+              _ptr(keep["n_blk"]) if bl is not None else None,
+              keep["q_arena"].size, ta.size if ta is not None else 0, bl.size if bl is not None else 0,
               _ptr(keep["t_rc"]) if "t_rc" in keep else None)
     return b, keep
 
@@ -102,6 +104,11 @@ class Context:
     def set_scoring(self, scoring):
         self._check(self._L.gba_set_scoring(self._h, C.byref(scoring)))
         self.scoring = scoring
+
+    def set_guide_producer(self, params):
+        """gba_set_guide_producer: batches without "blocks" get their guides from the device's own
+        chaining of exact matches (SdpParams from make_sdp_params; None switches it off)."""
+        self._check(self._L.gba_set_guide_producer(self._h, C.byref(params) if params is not None else None))
 
     def set_reference(self, ref):
         """Keep `ref` (bytes / uint8 array, the genome as ASCII) in device memory; batches without a
@@ -270,10 +277,12 @@ class Context:
         n = int(dbatch["n_pairs"])
         ta = dbatch.get("t_arena")
         trc = dbatch.get("t_rc")
+        gb = dbatch.get("blocks")         # absent: guides made on the device (set_guide_producer)
         b = Batch(n, dbatch["q_arena"].data_ptr(), dbatch["q_off"].data_ptr(), dbatch["q_len"].data_ptr(),
                   ta.data_ptr() if ta is not None else None, dbatch["t_off"].data_ptr(), dbatch["t_len"].data_ptr(),
-                  dbatch["blocks"].data_ptr(), dbatch["blk_off"].data_ptr(), dbatch["n_blk"].data_ptr(),
-                  dbatch["q_arena"].numel(), ta.numel() if ta is not None else 0, dbatch["blocks"].shape[0],
+                  gb.data_ptr() if gb is not None else None, dbatch["blk_off"].data_ptr() if gb is not None else None,
+                  dbatch["n_blk"].data_ptr() if gb is not None else None,
+                  dbatch["q_arena"].numel(), ta.numel() if ta is not None else 0, gb.shape[0] if gb is not None else 0,
                   trc.data_ptr() if trc is not None else None)
         assert out_pairs.numel() * out_pairs.element_size() >= n * PAIR_RESULT_DT.itemsize
         r = Results(out_pairs.data_ptr(), out_blocks.data_ptr() if out_blocks is not None else None,
@@ -314,6 +323,10 @@ class HostPipeline:
         for c in self.ctxs:
             c.set_scoring(scoring)
 
+    def set_guide_producer(self, params):
+        for c in self.ctxs:
+            c.set_guide_producer(params)
+
     def set_reference(self, ref):
         for c in self.ctxs:
             c.set_reference(ref)
@@ -346,10 +359,12 @@ def to_device(batch, device="cuda:0"):
     for k in ("q_arena", "t_arena", "t_rc"):
         if batch.get(k) is not None:
             d[k] = torch.from_numpy(np.ascontiguousarray(batch[k], dtype=np.uint8)).to(device)
-    for k in ("q_off", "t_off", "blk_off"):
+    guides = batch.get("blocks") is not None      # absent: sequences only (guides made on the device)
+    for k in ("q_off", "t_off") + (("blk_off",) if guides else ()):
         d[k] = torch.from_numpy(np.ascontiguousarray(batch[k], dtype=np.uint64).view(np.int64)).to(device)
-    for k in ("q_len", "t_len", "n_blk"):
+    for k in ("q_len", "t_len") + (("n_blk",) if guides else ()):
         d[k] = torch.from_numpy(np.ascontiguousarray(batch[k], dtype=np.uint32).view(np.int32)).to(device)
-    blk = np.ascontiguousarray(batch["blocks"], dtype=BLOCK_DT)
-    d["blocks"] = torch.from_numpy(blk.view(np.uint32).reshape(-1, 3).view(np.int32)).to(device)
+    if guides:
+        blk = np.ascontiguousarray(batch["blocks"], dtype=BLOCK_DT)
+        d["blocks"] = torch.from_numpy(blk.view(np.uint32).reshape(-1, 3).view(np.int32)).to(device)
     return d

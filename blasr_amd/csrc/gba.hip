@@ -92,6 +92,7 @@ struct Dev {                  // per-batch device state, SoA per pair
     const uint64_t *q_off, *t_off, *blk_off;
     const uint32_t *q_len, *t_len, *n_blk;
     const gba_block *blocks;
+    const int32_t *guide_status;   // guides made by the library itself: why a pair has none (null: the caller's guides)
     // per pair
     int32_t *status;
     uint32_t *qS, *tS, *Q, *T, *rows, *cols, *wcap, *span, *lo_last, *cls, *order, *recdw;
@@ -171,7 +172,7 @@ __global__ void k_meta(Dev d, int mode, int kband_k, uint32_t score_a, uint32_t 
     } else {
         nb = d.n_blk[p];
         const uint64_t bo = d.blk_off[p];
-        if (nb == 0) st = GBA_PAIR_EMPTY_GUIDE;
+        if (nb == 0) st = d.guide_status && d.guide_status[p] != GBA_PAIR_OK ? d.guide_status[p] : GBA_PAIR_EMPTY_GUIDE;
         else if (bo > d.n_blocks_total || nb > d.n_blocks_total - bo) { st = GBA_PAIR_BAD_GUIDE; nb = 0; }
         else if (st != GBA_PAIR_OK) nb = 0;
         else {
@@ -2134,6 +2135,9 @@ struct gba_ctx {
     uint32_t sdp_queue = 1024;       // hits queued per tile (env GBA_SDP_QUEUE, 64..16384)
     uint32_t sdp_tile_max = 2048;
     uint32_t sdp_slots_per_pos = 4;
+    gba_sdp_params guide_sp;         // gba_set_guide_producer: batches without guide blocks get their guides from gba_sdp's chains
+    bool have_guide_sp = false;
+    const int32_t *cur_guide_status = nullptr;   // set around run_device for such a batch
     gba_scoring sc;
     FillConst fc;
     TbConst tbc;
@@ -2153,9 +2157,10 @@ struct gba_ctx {
     Buf b_pair32[14], b_pair64[5], b_needed;
     Slot slot[NSLOT];
     // host-buffer batches: device copies of the caller's batch, the copy streams, the worker thread
-    Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res, s_cigoff;
+    Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res, s_cigoff, s_gout;
     hipStream_t s_in = nullptr, s_out = nullptr;     // host-to-device and device-to-host copies, beside the kernels
     std::vector<hipEvent_t> ev_in;                   // per part: its inputs have arrived
+    std::vector<hipEvent_t> ev_sdp;                  // per part of the guide producer: its sequences have arrived
     std::vector<void *> host_allocs;                 // gba_host_alloc
     uint64_t *h_needed = nullptr;    // pinned
     bool in_flight = false;          // a host-buffer batch has been submitted and not yet waited for
@@ -2233,6 +2238,7 @@ Dev sub_dev(const Dev &g, uint32_t p0, uint32_t cnt, Slot &sl)
     d.n = cnt;
     d.q_off += p0; d.t_off += p0; d.blk_off += p0; d.q_len += p0; d.t_len += p0; d.n_blk += p0;
     if (d.t_rc) d.t_rc += p0;
+    if (d.guide_status) d.guide_status += p0;
     d.status += p0; d.qS += p0; d.tS += p0; d.Q += p0; d.T += p0; d.rows += p0; d.cols += p0; d.wcap += p0;
     d.span += p0; d.lo_last += p0; d.cls += p0; d.order += p0; d.recdw += p0;
     d.row_off += p0; d.col_off += p0; d.word_off += p0; d.rec_off += p0; d.ncells += p0; d.dp_score += p0;
@@ -2364,9 +2370,12 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
 
 // A batch with pairs must bring every array the kernels index (the target arena may be absent:
 // windows of the ctx reference; the strand flags are optional).
-bool batch_complete(const gba_batch *b)
+bool batch_complete(const gba_ctx *c, const gba_batch *b)
 {
-    return b->n_pairs == 0 || (b->q_arena && b->blocks && b->q_off && b->t_off && b->blk_off && b->q_len && b->t_len && b->n_blk);
+    if (b->n_pairs == 0) return true;
+    if (!b->q_arena || !b->q_off || !b->t_off || !b->q_len || !b->t_len) return false;
+    if (!b->blocks) return c->have_guide_sp;       // the guides are made on the device
+    return b->blk_off && b->n_blk;
 }
 
 // What the timing of a batch is made of, folded in part by part.
@@ -2407,7 +2416,7 @@ struct HostIO {
 // the per-pair arrays of the part and the stretch of each arena its pairs point into (arenas are
 // normally laid out in pair order, so consecutive parts need consecutive stretches; whatever lies
 // between the stretch on the device and the new one is copied too, so one interval stays valid).
-int stage_part(gba_ctx *c, HostIO &io, uint32_t first, uint32_t cnt, hipEvent_t done)
+int stage_part(gba_ctx *c, HostIO &io, uint32_t first, uint32_t cnt, hipEvent_t done, bool arenas_only = false)
 {
     const gba_batch &b = *io.hb;
     hipStream_t st = c->s_in;
@@ -2420,7 +2429,7 @@ int stage_part(gba_ctx *c, HostIO &io, uint32_t first, uint32_t cnt, hipEvent_t 
     struct { Buf *buf; const void *src; size_t esz; } per_pair[] = {
         {&c->s_qoff, b.q_off, 8}, {&c->s_toff, b.t_off, 8}, {&c->s_boff, b.blk_off, 8},
         {&c->s_qlen, b.q_len, 4}, {&c->s_tlen, b.t_len, 4}, {&c->s_nblk, b.n_blk, 4}, {&c->s_trc, b.t_rc, 1}};
-    for (int k = 0; k < 7; k++) {
+    for (int k = 0; k < 7 && !arenas_only; k++) {
         auto &x = per_pair[k];
         if (!x.src) continue;
         int rc = move((char *)x.buf->ptr + (size_t)first * x.esz, (const char *)x.src + (size_t)first * x.esz, (size_t)cnt * x.esz);
@@ -2544,6 +2553,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
     }
     g.q_off = b->q_off; g.t_off = b->t_off; g.blk_off = b->blk_off;
     g.q_len = b->q_len; g.t_len = b->t_len; g.n_blk = b->n_blk;
+    g.guide_status = c->cur_guide_status;
     g.status = (int32_t *)c->b_pair32[0].ptr;
     g.qS = (uint32_t *)c->b_pair32[1].ptr; g.tS = (uint32_t *)c->b_pair32[2].ptr;
     g.Q = (uint32_t *)c->b_pair32[3].ptr; g.T = (uint32_t *)c->b_pair32[4].ptr;
@@ -2651,17 +2661,22 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
 // blocks per pair, until the part's block offsets are known).
 constexpr uint32_t SDP_PART = 32768;
 
-int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides *out)
+// io: the sequences are still in host memory (the per-pair arrays are on the device): once the longest
+// read and window are known, the arena stretch of every part is queued on the copy stream, and a part's
+// kernels wait only for their own stretch, so the sequences travel under the kernels of the parts before.
+uint32_t sdp_part_size(uint32_t n) { return n < SDP_PART ? n : SDP_PART; }
+
+int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides *out, HostIO *io = nullptr)
 {
     if (sp->tuple_size < 4 || sp->tuple_size > 15 || sp->match < 1 || sp->match > 127 || sp->ins < 0 || sp->ins > 127 ||
-        sp->del < 0 || sp->del > 127 || sp->max_fragments < 1 || sp->max_fragments > 4096) return GBA_E_UNSUPPORTED;
+        sp->del < 0 || sp->del > 127 || sp->max_fragments < 1 || sp->max_fragments > 4096) return GBA_E_UNSUPPORTED;      // sdp_params_ok
     const uint32_t n = b->n_pairs;
     out->blocks_needed = 0;
     if (n == 0) return GBA_OK;
     HIPCHK(c, hipSetDevice(c->device));
     Slot &sl = c->slot[0];
     hipStream_t s = sl.s;
-    const uint32_t per = n < SDP_PART ? n : SDP_PART;
+    const uint32_t per = sdp_part_size(n);
     { int rc = ensure(c, c->b_pair32[0], (size_t)per * 4); if (rc) return rc; }
     { int rc = ensure(c, c->b_needed, 16); if (rc) return rc; }
     uint64_t *needed = (uint64_t *)c->b_needed.ptr;
@@ -2706,12 +2721,25 @@ int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides
     { int rc = ensure(c, sl.b_blk, (size_t)per * k.max_fragments * sizeof(gba_block) + 16); if (rc) return rc; }
     { int rc = ensure(c, sl.b_guide, (size_t)per * k.cap * sizeof(uint2) + 16); if (rc) return rc; }
     uint32_t *nfrag = (uint32_t *)c->b_pair32[0].ptr;
+    if (io) {
+        const uint32_t nparts = (n + per - 1) / per;
+        while (c->ev_sdp.size() < nparts) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->ev_sdp.push_back(e);
+        }
+        for (uint32_t h = 0; h < nparts; h++) {
+            const uint32_t f = h * per;
+            int rc = stage_part(c, *io, f, n - f < per ? n - f : per, c->ev_sdp[h], true); if (rc) return rc;
+        }
+    }
     // the parts follow each other on the stream without the host in between; they share the scratch
     for (uint32_t first = 0; first < n; first += per) {
         const uint32_t cnt = n - first < per ? n - first : per;
         SdpIn pin = in;
         pin.q_off += first; pin.t_off += first; pin.q_len += first; pin.t_len += first;
         if (pin.t_rc) pin.t_rc += first;
+        if (io) HIPCHK(c, hipStreamWaitEvent(s, c->ev_sdp[first / per], 0));
         hipLaunchKernelGGL(k_sdp_match, dim3(cnt), dim3(SDP_THREADS), lds, s, pin, k, out->status + first, (uint2 *)sl.b_guide.ptr, nfrag);
         {
             const uint32_t small = k.cap < SDP_SMALL ? k.cap : SDP_SMALL;
@@ -2730,6 +2758,41 @@ int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides
     HIPCHK(c, hipStreamSynchronize(s));
     out->blocks_needed = c->h_needed[0];
     return out->blocks_needed > out->blocks_capacity ? GBA_E_NOSPACE : GBA_OK;
+}
+
+bool sdp_params_ok(const gba_sdp_params *sp)
+{
+    return !(sp->tuple_size < 4 || sp->tuple_size > 15 || sp->match < 1 || sp->match > 127 || sp->ins < 0 || sp->ins > 127 ||
+             sp->del < 0 || sp->del > 127 || sp->max_fragments < 1 || sp->max_fragments > 4096);
+}
+
+// Guides for a device batch that brings none (gba_set_guide_producer): the chains of run_sdp go to
+// buffers of the ctx and *db is completed with them.  `hint`: blocks to make room for at first (0: the
+// room of the batch before); when that is too little the producer says how many there are and runs again.
+int make_guides(gba_ctx *c, gba_batch *db, uint64_t hint, HostIO *io = nullptr)
+{
+    const uint32_t n = db->n_pairs;
+    int rc;
+    if ((rc = ensure(c, c->s_gout, (size_t)n * 8 + 16))) return rc;
+    if ((rc = ensure(c, c->s_nblk, (size_t)n * 4 + 16))) return rc;
+    if ((rc = ensure(c, c->s_boff, (size_t)n * 8 + 16))) return rc;
+    gba_guides dg;
+    dg.status = (int32_t *)c->s_gout.ptr; dg.chain_score = dg.status + n;
+    dg.n_blk = (uint32_t *)c->s_nblk.ptr; dg.blk_off = (uint64_t *)c->s_boff.ptr;
+    uint64_t cap = c->s_blk.cap / sizeof(gba_block);
+    if (cap < hint) cap = hint;
+    if (cap < (uint64_t)n * 16) cap = (uint64_t)n * 16;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rc = ensure(c, c->s_blk, (size_t)cap * sizeof(gba_block) + 16))) return rc;
+        dg.blocks = (gba_block *)c->s_blk.ptr; dg.blocks_capacity = cap; dg.blocks_needed = 0;
+        rc = run_sdp(c, db, &c->guide_sp, &dg, io);
+        if (rc != GBA_E_NOSPACE) break;
+        cap = dg.blocks_needed + dg.blocks_needed / 16;
+    }
+    if (rc != GBA_OK) return rc;
+    db->blocks = dg.blocks; db->blk_off = dg.blk_off; db->n_blk = dg.n_blk; db->n_blocks_total = dg.blocks_needed;
+    c->cur_guide_status = dg.status;
+    return GBA_OK;
 }
 
 }  // namespace
@@ -2833,13 +2896,14 @@ void gba_destroy(gba_ctx *c)
     if (c->s_in) { (void)hipStreamSynchronize(c->s_in); (void)hipStreamDestroy(c->s_in); }
     if (c->s_out) { (void)hipStreamSynchronize(c->s_out); (void)hipStreamDestroy(c->s_out); }
     for (hipEvent_t e : c->ev_in) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_sdp) (void)hipEventDestroy(e);
     for (void *p : c->host_allocs) (void)hipHostFree(p);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &b : c->b_pair32) release(b);
     for (auto &b : c->b_pair64) release(b);
     Buf *bs[] = {&c->b_ref, &c->s_trc, &c->b_needed,
                  &c->s_q, &c->s_t, &c->s_blk, &c->s_qoff, &c->s_toff, &c->s_boff, &c->s_qlen, &c->s_tlen,
-                 &c->s_nblk, &c->s_res, &c->s_cigoff};
+                 &c->s_nblk, &c->s_res, &c->s_cigoff, &c->s_gout};
     for (Buf *b : bs) release(*b);
     if (c->h_needed) (void)hipHostFree(c->h_needed);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -2943,8 +3007,15 @@ int gba_submit_device(gba_ctx *c, const gba_batch *b, gba_results *out)
     if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
     if (b->n_pairs && (!out->pairs || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
     if (out->cigar_ops && !out->cigar_off) return GBA_E_INVALID;
-    if (!batch_complete(b)) return GBA_E_INVALID;
+    if (!batch_complete(c, b)) return GBA_E_INVALID;
     if (!b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
+    if (b->n_pairs && !b->blocks) {                  // guides made here first (gba_set_guide_producer)
+        gba_batch db = *b;
+        int rc = make_guides(c, &db, 0);
+        if (rc == GBA_OK) rc = run_device(c, &db, out);
+        c->cur_guide_status = nullptr;
+        return rc;
+    }
     return run_device(c, b, out);
 }
 
@@ -2954,8 +3025,9 @@ int gba_submit_device_noalloc(gba_ctx *c, const gba_batch *b, gba_results *out)
     if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
     if (b->n_pairs && (!out->pairs || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
     if (out->cigar_ops && !out->cigar_off) return GBA_E_INVALID;
-    if (!batch_complete(b)) return GBA_E_INVALID;
+    if (!batch_complete(c, b)) return GBA_E_INVALID;
     if (!b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
+    if (b->n_pairs && !b->blocks) return GBA_E_INVALID;     // guide production allocates: not for this entry point
     if (!c->fixed_base) return GBA_E_HIP;             // hipGetSymbolAddress failed in gba_create
     // The ctx's own (allocated, grow-only) buffers are set aside for the duration of the call and the
     // same pipeline runs on buffers carved from the fixed scratch, as one part on slot 0.
@@ -3007,6 +3079,23 @@ static int run_host_batch(gba_ctx *c, const gba_batch *b, gba_results *out)
     dr.cigar_capacity = out->cigar_capacity; dr.cigar_flags = out->cigar_flags;
     HostIO io;
     io.hb = b; io.hout = out; io.d_res = dr.pairs;
+    gba_batch hb_noguides;
+    if (!b->blocks) {
+        // No guides in the batch: they are made on the device from the sequences (nothing of a guide ever
+        // crosses the link).  The per-pair arrays go first; the arenas follow inside run_sdp, under the
+        // producer's kernels; the pipeline below then finds everything in place.
+        hb_noguides = *b;
+        hb_noguides.blk_off = nullptr; hb_noguides.n_blk = nullptr;         // whatever the caller left there is not a guide
+        io.hb = &hb_noguides;
+        hipStream_t s0 = c->slot[0].s;
+        struct { Buf *buf; const void *src; size_t bytes; } in[] = {
+            {&c->s_qoff, b->q_off, (size_t)n * 8}, {&c->s_toff, b->t_off, (size_t)n * 8},
+            {&c->s_qlen, b->q_len, (size_t)n * 4}, {&c->s_tlen, b->t_len, (size_t)n * 4}, {&c->s_trc, b->t_rc, b->t_rc ? (size_t)n : 0}};
+        for (auto &x : in) if (x.bytes) HIPCHK(c, hipMemcpyAsync(x.buf->ptr, x.src, x.bytes, hipMemcpyHostToDevice, s0));
+        uint64_t qsum = 0;
+        for (uint32_t p = 0; p < n; p++) qsum += b->q_len[p];
+        if ((rc = make_guides(c, &db, qsum / 16 + n, &io))) { c->cur_guide_status = nullptr; return rc; }
+    }
     if (cig) io.d_cigoff = (uint64_t *)c->s_cigoff.ptr;
     // Page-locked arenas (gba_host_alloc, or pinned / registered by the caller) are copied by the copy
     // engines without the calling thread; when the runtime also has a hardware queue to spare for the
@@ -3019,8 +3108,9 @@ static int run_host_batch(gba_ctx *c, const gba_batch *b, gba_results *out)
         return a.type == hipMemoryTypeHost;
     };
     const char *hq = getenv("GPU_MAX_HW_QUEUES");
-    io.all_ahead = hq && atoi(hq) >= 8 && pinned(b->q_arena) && pinned(b->blocks) && (!b->t_arena || pinned(b->t_arena));
+    io.all_ahead = hq && atoi(hq) >= 8 && pinned(b->q_arena) && (!b->blocks || pinned(b->blocks)) && (!b->t_arena || pinned(b->t_arena));
     rc = run_device(c, &db, &dr, &io);
+    c->cur_guide_status = nullptr;
     out->blocks_needed = dr.blocks_needed; out->cigar_needed = dr.cigar_needed;
     return rc;
 }
@@ -3051,7 +3141,7 @@ int gba_submit(gba_ctx *c, const gba_batch *b, gba_results *out)
 {
     if (!c || !b || !out) return GBA_E_INVALID;
     if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
-    if (!batch_complete(b)) return GBA_E_INVALID;
+    if (!batch_complete(c, b)) return GBA_E_INVALID;
     if (b->n_pairs && (!out->pairs || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
     if (out->cigar_ops && !out->cigar_off) return GBA_E_INVALID;
     if (b->n_pairs && !b->t_arena && !c->b_ref.ptr) return GBA_E_STATE;
@@ -3106,6 +3196,16 @@ void gba_host_free(gba_ctx *c, void *ptr)
             c->host_allocs.erase(c->host_allocs.begin() + (long)i);
             return;
         }
+}
+
+int gba_set_guide_producer(gba_ctx *c, const gba_sdp_params *sp)
+{
+    if (!c) return GBA_E_INVALID;
+    if (c->in_flight) return GBA_E_STATE;
+    if (!sp) { c->have_guide_sp = false; return GBA_OK; }
+    if (!sdp_params_ok(sp)) return GBA_E_UNSUPPORTED;
+    c->guide_sp = *sp; c->have_guide_sp = true;
+    return GBA_OK;
 }
 
 int gba_sdp_device(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides *out)

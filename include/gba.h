@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GBA_VERSION 330   /* major*10000 + minor*100 + patch */
+#define GBA_VERSION 340   /* major*10000 + minor*100 + patch */
 
 /* return codes of the entry points */
 enum {
@@ -288,6 +288,18 @@ int gba_sdp_device(gba_ctx *ctx, const gba_batch *device_batch, const gba_sdp_pa
 /* The same for host buffers (every pointer of the batch and of the guides is a host pointer): copies the
  * sequences in, returns when the guides have been copied out. */
 int gba_sdp(gba_ctx *ctx, const gba_batch *host_batch, const gba_sdp_params *params, gba_guides *host_out);
+
+/* From sequences to refined alignments in one call.  With a guide producer set (params != NULL; NULL
+ * switches it off again), gba_submit and gba_submit_device accept a batch whose `blocks` is NULL
+ * (blk_off and n_blk are then ignored): the guide of every pair is made on the device as gba_sdp_device
+ * makes it and handed to the refine stage where it lies, which is what AlignIntervals followed by
+ * RefineAlignments do per candidate (iblasr/BlasrAlignImpl.hpp:980-987, then
+ * iblasr/BlasrUtilsImpl.hpp:905-923); no guide crosses the link in either direction.  A pair without a
+ * guide gets the producer's reason as its status (GBA_PAIR_EMPTY_GUIDE, GBA_PAIR_TOO_MANY,
+ * GBA_PAIR_TOO_LONG, GBA_PAIR_BAD_GUIDE).  Batches that bring their own blocks run as before.
+ * GBA_E_UNSUPPORTED for values outside gba_sdp_params' ranges; gba_submit_device_noalloc does not
+ * take such batches (GBA_E_INVALID). */
+int gba_set_guide_producer(gba_ctx *ctx, const gba_sdp_params *params);
 
 /* Keeps a copy of the reference (genome, ASCII; `ref` is a host pointer) in device
  * memory for batches whose t_arena is NULL; len == 0 drops it.  Replaces the

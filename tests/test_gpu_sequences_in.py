@@ -1,0 +1,153 @@
+"""From sequences to refined alignments in one call (gba_set_guide_producer + a batch without guide
+blocks), through the C-ABI: the results must be those of the two stages called one after the other
+(gba_sdp, then gba_submit on its guides), which the other tests check against the two oracles; a few
+pairs are checked against the oracles directly as well."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RESULT_FIELDS = ["dp_score", "score", "q_pos", "t_pos", "n_blk", "blk_off", "n_match", "n_mismatch", "n_ins", "n_del",
+                 "rows", "cols", "ncells", "extra_score", "q_start", "q_end", "t_start", "t_end"]
+SEQ_KEYS = ("n_pairs", "q_arena", "q_off", "q_len", "t_arena", "t_off", "t_len", "t_rc")
+
+
+@pytest.fixture(scope="module")
+def api():
+    from blasr_amd import api as a
+    return a
+
+
+def _sequences_only(batch):
+    return {k: batch[k] for k in SEQ_KEYS if batch.get(k) is not None}
+
+
+def _two_calls(ctx, seqs, sp):
+    status, score, n_blk, off, blocks, rc = ctx.sdp_host(seqs, sp)
+    assert rc == 0
+    guided = dict(seqs, blocks=blocks if len(blocks) else np.zeros(1, blocks.dtype), blk_off=off, n_blk=n_blk)
+    pairs, out_blocks, rc = ctx.refine_host(guided)
+    assert rc == 0
+    return status, pairs, out_blocks
+
+
+def _same(status, want, want_blocks, got, got_blocks):
+    ok = status == 0
+    # a pair without a guide carries the producer's reason, every other pair is the two-call result
+    assert np.array_equal(got["status"][~ok], status[~ok])
+    assert np.array_equal(got["status"][ok], want["status"][ok])
+    for f in RESULT_FIELDS:
+        assert np.array_equal(got[f][ok], want[f][ok]), f
+    assert np.array_equal(got_blocks, want_blocks)
+
+
+def test_one_call_equals_two_calls(api, oracle, synth):
+    from blasr_amd import _lib
+    ctx = api.Context(0)
+    try:
+        batch = synth.generate(200, read_len=2500, seed=1717, len_jitter=1500, n_frac=0.01)
+        seqs = _sequences_only(batch)
+        # a read that matches nothing, and a budget of maximal matches that the longest pairs exceed
+        q0, l0 = int(seqs["q_off"][3]), int(seqs["q_len"][3])
+        seqs["q_arena"] = seqs["q_arena"].copy()
+        seqs["q_arena"][q0:q0 + l0] = ord("N")
+        sp = api.make_sdp_params(max_fragments=72)
+        for kw in (dict(), dict(mode=_lib.MODE_AFFINE, band=16, affine_open=10, affine_extend=1)):
+            ctx.set_scoring(api.make_scoring(**kw))
+            ctx.set_guide_producer(None)
+            status, want, want_blocks = _two_calls(ctx, seqs, sp)
+            assert int(status[3]) == _lib.PAIR_EMPTY_GUIDE and (status == _lib.PAIR_TOO_MANY).any() and (status == 0).sum() > 40
+            with pytest.raises(api.GbaError):
+                ctx.refine_host(seqs)                      # no guides and no producer
+            ctx.set_guide_producer(sp)
+            got, got_blocks, rc = ctx.refine_host(seqs)
+            assert rc == 0
+            _same(status, want, want_blocks, got, got_blocks)
+            # leftovers in blk_off / n_blk of a batch without blocks are not a guide
+            junk = dict(seqs, blk_off=np.full(200, 7, np.uint64), n_blk=np.full(200, 9, np.uint32))
+            got2, got_blocks2, rc = ctx.refine_host(junk)
+            _same(status, want, want_blocks, got2, got_blocks2)
+            # batches that bring guides are not touched by the producer
+            again, again_blocks, rc = ctx.refine_host(batch)
+            ctx.set_guide_producer(None)
+            plain, plain_blocks, rc = ctx.refine_host(batch)
+            assert again.tobytes() == plain.tobytes() and np.array_equal(again_blocks, plain_blocks)
+        # against the oracles, both stages
+        ctx.set_scoring(api.make_scoring())
+        ctx.set_guide_producer(sp)
+        got, got_blocks, rc = ctx.refine_host(seqs)
+        osp = oracle.make_sdp_params(max_fragments=72)
+        checked = 0
+        for p in range(0, 200, 9):
+            q, t, _ = synth.pair(batch, p)
+            if p == 3:
+                continue
+            q, t = bytes(q), bytes(t)
+            st, guide, _, _ = oracle.sdp_chain(q, t, osp)
+            assert st == int(status[p])
+            if st != 0:
+                continue
+            er, eb = oracle.align(q, t, guide, oracle.make_params())
+            r = got[p]
+            assert (int(r["status"]), int(r["score"]), int(r["n_blk"]), int(r["q_pos"]), int(r["t_pos"])) == \
+                   (0, er["score"], er["n_blk"], er["q_pos"], er["t_pos"])
+            kb = got_blocks[int(r["blk_off"]):int(r["blk_off"]) + int(r["n_blk"])]
+            assert np.array_equal(kb["q_pos"], eb["q_pos"]) and np.array_equal(kb["t_pos"], eb["t_pos"]) and np.array_equal(kb["length"], eb["length"])
+            checked += 1
+        assert checked >= 5
+    finally:
+        ctx.close()
+
+
+def test_windows_of_the_reference_in_parts_to_intervals(api, synth, monkeypatch):
+    """Reads and windows of the resident reference on both strands, a batch run in several parts, no block
+    arena: sequences in, interval records out; and the device entry point on the same batch."""
+    import torch
+    from blasr_amd import _lib
+    monkeypatch.setenv("GBA_PART_PAIRS", "1024")
+    ctx = api.Context(0)
+    try:
+        ref = synth.reference(400_000, 5)
+        batch = synth.generate(3000, read_len=700, seed=99, len_jitter=300, ref=ref, ref_len=400_000, share_reads=True, decoy_every=4)
+        win = synth.as_windows(batch)
+        assert win.get("t_arena") is None and win["t_rc"].any()
+        ctx.set_reference(ref)
+        ctx.set_scoring(api.make_scoring())
+        seqs = _sequences_only(win)
+        sp = api.make_sdp_params(tuple_size=9)
+        status, want, want_blocks = _two_calls(ctx, seqs, sp)
+        assert (status == 0).sum() > 700 and (status != 0).sum() > 700      # true windows and decoys
+        ctx.set_guide_producer(sp)
+        got, got_blocks, rc = ctx.refine_host(seqs)
+        assert rc == 0
+        _same(status, want, want_blocks, got, got_blocks)
+        only, rc = ctx.refine_host_intervals(seqs)
+        assert rc == 0 and only.tobytes() == got.tobytes()
+        # buffers already on the device
+        n = int(seqs["n_pairs"])
+        db = api.to_device(seqs)
+        assert "blocks" not in db
+        out_pairs = torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0")
+        out_blocks = torch.zeros((len(want_blocks) + 8, 3), dtype=torch.int32, device="cuda:0")
+        rc, needed = ctx.refine_device(db, out_pairs, out_blocks)
+        assert rc == 0 and needed == len(want_blocks)
+        dev = np.frombuffer(out_pairs.cpu().numpy().tobytes(), dtype=_lib.PAIR_RESULT_DT)
+        dev_blocks = out_blocks.cpu().numpy()[:needed].reshape(-1).view(_lib.BLOCK_DT)
+        _same(status, want, want_blocks, dev, dev_blocks)
+        with pytest.raises(api.GbaError):
+            ctx.refine_device(db, out_pairs, out_blocks, no_alloc=True)
+    finally:
+        ctx.close()
+
+
+def test_producer_parameters_are_checked(api):
+    ctx = api.Context(0)
+    try:
+        with pytest.raises(api.GbaError):
+            ctx.set_guide_producer(api.make_sdp_params(tuple_size=3))
+        with pytest.raises(api.GbaError):
+            ctx.set_guide_producer(api.make_sdp_params(max_fragments=5000))
+        ctx.set_guide_producer(api.make_sdp_params())
+        ctx.set_guide_producer(None)
+    finally:
+        ctx.close()

@@ -1,0 +1,13 @@
+#!/bin/bash
+# From-sequences host path: one context alone, then two and three contexts in turn (the host-to-host child of bench.py run directly).
+export GBA_NO_TORCH=1 GPU_MAX_HW_QUEUES=16
+timeout -k 10 300 python tools/fromseq_one.py || exit 1
+for ctxs in 2 3; do
+  echo "== contexts $ctxs"
+  timeout -k 10 300 python bench.py --host-child --workload c2_10kb_linear --pairs 491520 --host-steps 6 --host-contexts $ctxs --host-blocks 520000000 \
+    | python -c "
+import json,sys
+h=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('guided ms', round(h['ms_per_step'],1), 'intervals ms', round(h['intervals_ms_per_step'],1), {k: round(v['ms_per_step'],1) for k,v in h['from_sequences'].items()})
+" || exit 1
+done
