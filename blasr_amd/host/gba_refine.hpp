@@ -304,6 +304,75 @@ inline int SDPAlignCandidates(const std::string &read, std::vector<AlignmentCand
     return GBA_OK;
 }
 
+// SDPAlign and RefineAlignment for every candidate of a read in ONE submit (gba_set_guide_producer): the batch
+// carries the read and the candidates' windows, the guides are made on the device and refined where they lie; no
+// guide travels.  The candidates end up as SDPAlignCandidates followed by RefineAlignments leaves them (blocks,
+// score, counts, tAlignedSeq / qAlignedSeq cut to the refined stretch, positions); a candidate without a guide
+// keeps none and gets the producer's reason as its status.  wantBlocks false: interval output.
+inline int AlignAndRefineCandidates(const std::string &read, std::vector<AlignmentCandidate *> &alignmentPtrs,
+                                    const MappingParameters &params, gba_ctx *ctx, bool wantBlocks = true)
+{
+    const uint32_t n = (uint32_t)alignmentPtrs.size();
+    if (n == 0) return GBA_OK;
+    std::string t_arena;
+    std::vector<uint64_t> q_off(n), t_off(n);
+    std::vector<uint32_t> q_len(n), t_len(n);
+    uint64_t cap = n;
+    for (uint32_t i = 0; i < n; i++) {
+        const AlignmentCandidate &c = *alignmentPtrs[i];
+        if (c.qAlignedSeqPos > read.size()) throw std::out_of_range("candidate starts behind its read");
+        q_off[i] = c.qAlignedSeqPos;
+        q_len[i] = c.qAlignedSeqLength ? c.qAlignedSeqLength : (uint32_t)(read.size() - c.qAlignedSeqPos);
+        t_off[i] = t_arena.size(); t_len[i] = (uint32_t)c.tAlignedSeq.size();
+        t_arena += c.tAlignedSeq;
+        cap += q_len[i];
+    }
+    if (t_arena.empty()) t_arena.push_back('N');
+    gba_scoring sc = ScoringFromParams(params);
+    int rc = gba_set_scoring(ctx, &sc);
+    if (rc != GBA_OK) return rc;
+    gba_sdp_params sp{params.sdpTupleSize, params.sdpIns, params.sdpDel, -params.match, params.sdpMaxFragments};
+    if ((rc = gba_set_guide_producer(ctx, &sp)) != GBA_OK) return rc;
+    gba_batch b{};
+    b.n_pairs = n;
+    b.q_arena = (const uint8_t *)read.data(); b.q_off = q_off.data(); b.q_len = q_len.data(); b.q_arena_bytes = read.size();
+    b.t_arena = (const uint8_t *)t_arena.data(); b.t_off = t_off.data(); b.t_len = t_len.data(); b.t_arena_bytes = t_arena.size();
+    if (!wantBlocks) cap = 0;
+    std::vector<gba_pair_result> pairs(n);
+    std::vector<gba_block> out(cap);
+    gba_results r{pairs.data(), wantBlocks ? out.data() : nullptr, cap, 0};
+    if ((rc = gba_submit(ctx, &b, &r)) == GBA_OK) rc = gba_wait(ctx);
+    (void)gba_set_guide_producer(ctx, nullptr);
+    if (rc != GBA_OK) return rc;
+    for (uint32_t i = 0; i < n; i++) {
+        AlignmentCandidate &c = *alignmentPtrs[i];
+        const gba_pair_result &p = pairs[i];
+        c.status = p.status;
+        c.blocks.clear();
+        c.nBlocks = 0;
+        c.qPos = c.tPos = 0;
+        if (p.status != GBA_PAIR_OK) continue;
+        for (uint32_t k = 0; k < p.n_blk && wantBlocks; k++) {
+            const gba_block &g = out[p.blk_off + k];
+            c.blocks.push_back(Block{g.q_pos, g.t_pos, g.length});
+        }
+        c.nBlocks = p.n_blk;
+        c.nMatch = p.n_match; c.nMismatch = p.n_mismatch; c.nIns = p.n_ins; c.nDel = p.n_del;
+        const uint64_t cols = (uint64_t)p.n_match + p.n_mismatch + p.n_ins + p.n_del;
+        c.pctSimilarity = cols ? (float)(p.n_match * 2.0 / (2.0 * cols) * 100.0) : 0.f;
+        c.score = p.score; c.nCells = p.ncells;
+        // the refined stretch starts at the chain's first anchor: that becomes the start of the aligned sequences
+        c.qStart = c.qAlignedSeqPos + p.q_start; c.qEnd = c.qAlignedSeqPos + p.q_end;
+        c.tStart = c.tAlignedSeqPos + p.t_start; c.tEnd = c.tAlignedSeqPos + p.t_end;
+        c.haveInterval = true;
+        c.qAlignedSeq = read.substr(q_off[i] + p.q_pos, p.rows);
+        c.tAlignedSeq = c.tAlignedSeq.substr(p.t_pos, p.cols);
+        c.qAlignedSeqPos += p.q_pos; c.tAlignedSeqPos += p.t_pos;
+        c.qAlignedSeqLength = p.rows; c.tAlignedSeqLength = p.cols;
+    }
+    return GBA_OK;
+}
+
 // The -global branch of RefineAlignment (:648-675) for all candidates of one read: the whole subread
 // against the whole tAlignedSeq in a diagonal band of half-width ComputeDrift(candidate), RemoveEndGaps,
 // rescoring with distScoreFn2; blocks, tPos, qPos (+ SubreadStart) and score are copied back and

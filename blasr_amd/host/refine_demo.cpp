@@ -8,6 +8,7 @@
 //            for each candidate (what a parsing loop does)
 //   global   run the -global branch (RefineGlobal) on each (read, candidate) instead
 //   sdp      the guides come from the device first (SDPAlignCandidates: the blocks of the input are ignored), then the batch
+//   fused    SDPAlign and RefineAlignment in one submit (AlignAndRefineCandidates; the blocks of the input are ignored)
 //   intervals  run without a block arena and print per candidate: status score nBlocks qStart qEnd tStart tEnd
 //   mapqv    no GPU: stdin is n, then "qStart qEnd rawProbScore" per candidate of ONE read; prints their mapQVs
 #include <cstdio>
@@ -19,7 +20,7 @@ int main(int argc, char **argv)
 {
     const std::string mode = argc > 1 ? argv[1] : "";
     const bool cigar = mode == "cigar", reuse = mode == "reuse", global = mode == "global", sdp = mode == "sdp";
-    const bool intervals = mode == "intervals";
+    const bool intervals = mode == "intervals", fused = mode == "fused";
     size_t n;
     if (!(std::cin >> n)) return 2;
     if (mode == "mapqv") {
@@ -57,6 +58,12 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < n && rc == GBA_OK; i++) {
             std::vector<gba::AlignmentCandidate *> one{&cands[i]};
             rc = gba::RefineAlignments(reads[i], one, params, ctx);
+        }
+    } else if (fused) {
+        params.sortRefinedAlignments = false;
+        for (size_t i = 0; i < n && rc == GBA_OK; i++) {
+            std::vector<gba::AlignmentCandidate *> one{&cands[i]};
+            rc = gba::AlignAndRefineCandidates(reads[i], one, params, ctx);
         }
     } else {
         if (sdp) {

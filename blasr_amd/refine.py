@@ -215,6 +215,63 @@ def SDPAlignCandidates(read: bytes, cands: List[AlignmentCandidate], params: Map
     return cands
 
 
+def AlignAndRefineCandidates(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx, want_blocks: bool = True):
+    """SDPAlign (AlignIntervals, /root/reference/iblasr/BlasrAlignImpl.hpp:980-987) and RefineAlignment
+    (/root/reference/iblasr/BlasrUtilsImpl.hpp:905-923) for every candidate of a read in ONE submit
+    (Context.set_guide_producer): the batch carries the read and the candidates' windows, the guides are made
+    on the device and refined where they lie; no guide travels.  The candidates end up as
+    SDPAlignCandidates followed by RefineAlignments leaves them; a candidate without a guide keeps no
+    blocks and gets the producer's reason as its status.  want_blocks False: interval output."""
+    n = len(cands)
+    if n == 0:
+        return cands
+    q_arena = np.frombuffer(read, dtype=np.uint8)
+    q_off = np.array([c.qAlignedSeqPos for c in cands], np.uint64)
+    q_len = np.array([c.qAlignedSeqLength or len(read) - c.qAlignedSeqPos for c in cands], np.uint32)
+    t_len = np.array([len(c.tAlignedSeq) for c in cands], np.uint32)
+    t_off = np.zeros(n, np.uint64); t_off[1:] = np.cumsum(t_len[:-1].astype(np.uint64))
+    t_arena = np.frombuffer(b"".join(c.tAlignedSeq for c in cands) or b"N", dtype=np.uint8)
+    batch = {"n_pairs": n, "q_arena": q_arena, "q_off": q_off, "q_len": q_len, "t_arena": t_arena, "t_off": t_off, "t_len": t_len}
+    ctx.set_scoring(scoring_from_params(params))
+    ctx.set_guide_producer(make_sdp_params(tuple_size=params.sdpTupleSize, ins=params.sdpIns, dele=params.sdpDel, match=-params.match,
+                                           max_fragments=params.sdpMaxFragments))
+    try:
+        if want_blocks:
+            pairs, blocks, rc = ctx.refine_host(batch)
+        else:
+            (pairs, rc), blocks = ctx.refine_host_intervals(batch), None
+    finally:
+        ctx.set_guide_producer(None)
+    for i, (c, r) in enumerate(zip(cands, pairs)):
+        c.status = int(r["status"])
+        c.blocks = np.zeros(0, dtype=BLOCK_DT)
+        c.nBlocks = 0
+        c.qPos = c.tPos = 0
+        if c.status != _lib.PAIR_OK:
+            continue
+        if blocks is not None:
+            c.blocks = blocks[int(r["blk_off"]):int(r["blk_off"]) + int(r["n_blk"])].copy()
+        c.nBlocks = int(r["n_blk"])
+        c.nMatch, c.nMismatch = int(r["n_match"]), int(r["n_mismatch"])
+        c.nIns, c.nDel = int(r["n_ins"]), int(r["n_del"])
+        cols = c.nMatch + c.nMismatch + c.nIns + c.nDel
+        c.pctSimilarity = (c.nMatch * 2.0) / (2 * cols) * 100.0 if cols else 0.0
+        c.score, c.nCells = int(r["score"]), int(r["ncells"])
+        # the refined stretch starts at the chain's first anchor: that becomes the start of the aligned sequences
+        qp, tp, rows, ncol = int(r["q_pos"]), int(r["t_pos"]), int(r["rows"]), int(r["cols"])
+        c.qInterval = (c.qAlignedSeqPos + int(r["q_start"]), c.qAlignedSeqPos + int(r["q_end"]))
+        c.tInterval = (c.tAlignedSeqPos + int(r["t_start"]), c.tAlignedSeqPos + int(r["t_end"]))
+        qo = int(q_off[i]) + qp
+        c.qAlignedSeq = read[qo:qo + rows]
+        c.tAlignedSeq = c.tAlignedSeq[tp:tp + ncol]
+        c.qAlignedSeqPos += qp
+        c.tAlignedSeqPos += tp
+        c.qAlignedSeqLength, c.tAlignedSeqLength = rows, ncol
+    if params.sortRefinedAlignments:
+        cands.sort(key=lambda c: c.score)
+    return cands
+
+
 def GuidesFromAnchorsOrSDP(read: bytes, cands: List[AlignmentCandidate], anchors: List[list], params: MappingParameters, ctx,
                            subreadLength: Optional[int] = None):
     """AlignIntervals' choice of the guide (/root/reference/iblasr/BlasrAlignImpl.hpp:768-1004): when

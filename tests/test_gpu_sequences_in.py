@@ -151,3 +151,45 @@ def test_producer_parameters_are_checked(api):
         ctx.set_guide_producer(None)
     finally:
         ctx.close()
+
+
+def test_host_mirrors_one_call_equals_two_calls(api, synth):
+    """refine.AlignAndRefineCandidates against SDPAlignCandidates + RefineAlignments, candidate by candidate;
+    the C++ mirror's two forms print the same lines."""
+    import subprocess
+    from blasr_amd import build, refine
+    batch = synth.generate(8, read_len=1800, len_jitter=600, seed=4711)
+    ctx = api.Context(0)
+    try:
+        params = refine.MappingParameters(sortRefinedAlignments=False)
+        lines = ["8"]
+        for i in range(8):
+            q, t, _ = synth.pair(batch, i)
+            read, window = bytes(q), bytes(t)
+            if i == 5:
+                window = b"N" * len(window)             # nothing to anchor on
+            lines.append("%s %s 0" % (read.decode(), window.decode()))
+
+            def cands():
+                return [refine.AlignmentCandidate(tAlignedSeq=window, tAlignedSeqPos=1000 + i, qAlignedSeqPos=0),
+                        refine.AlignmentCandidate(tAlignedSeq=window[40:], tAlignedSeqPos=2000, qAlignedSeqPos=25)]
+            two = refine.RefineAlignments(read, refine.SDPAlignCandidates(read, cands(), params, ctx), params, ctx)
+            one = refine.AlignAndRefineCandidates(read, cands(), params, ctx)
+            iv = refine.AlignAndRefineCandidates(read, cands(), params, ctx, want_blocks=False)
+            for a, b, c in zip(two, one, iv):
+                assert (a.status == 0) == (b.status == 0) == (c.status == 0) == (i != 5)
+                if a.status != 0:
+                    assert b.status == c.status == 1 and len(b.blocks) == 0
+                    continue
+                for f in ("score", "nCells", "nMatch", "nMismatch", "nIns", "nDel", "pctSimilarity", "qPos", "tPos", "qAlignedSeqPos",
+                          "tAlignedSeqPos", "qAlignedSeq", "tAlignedSeq", "qAlignedSeqLength", "tAlignedSeqLength", "qInterval", "tInterval", "nBlocks"):
+                    assert getattr(a, f) == getattr(b, f) == getattr(c, f), f
+                assert np.array_equal(a.blocks, b.blocks) and len(c.blocks) == 0
+    finally:
+        ctx.close()
+    text = "\n".join(lines) + "\n"
+    out = [subprocess.run([build.HOST_DEMO, mode], input=text, capture_output=True, text=True, timeout=120) for mode in ("sdp", "fused")]
+    assert out[0].returncode == 0 and out[1].returncode == 0, (out[0].stderr, out[1].stderr)
+    rows = [o.stdout.strip().split("\n") for o in out]
+    assert len(rows[0]) == 8 and rows[0][:5] + rows[0][6:] == rows[1][:5] + rows[1][6:]
+    assert rows[0][5].split()[0] != "0" and rows[1][5].split()[0] == "1"      # the pair without anchors
