@@ -95,6 +95,11 @@ class MultiGpuRefiner:
         for c in self.ctxs:
             c.set_reference(ref)
 
+    def set_guide_producer(self, params):
+        """Batches without "blocks" get their guides on the GPU that refines them (Context.set_guide_producer)."""
+        for c in self.ctxs:
+            c.set_guide_producer(params)
+
     def refine_host(self, batch):
         """Returns (pairs, blocks, rc) like Context.refine_host, for the whole batch."""
         n = int(batch["n_pairs"])

@@ -31,6 +31,15 @@ def test_multi_gpu_refiner_equals_one_context(oracle, synth, world):
         m.set_reference(ref)
         got_p, got_b, rc = m.refine_host(synth.as_windows(batch) | {"read_id": batch["read_id"]})
         assert rc == 0 and got_p.tobytes() == want_p.tobytes() and got_b.tobytes() == want_b.tobytes()
+        # and from the sequences alone: every context makes the guides of its own reads
+        seqs = {k: v for k, v in batch.items() if k not in ("blocks", "blk_off", "n_blk")}
+        sp = api.make_sdp_params()
+        one.set_guide_producer(sp)
+        want_p, want_b, rc = one.refine_host(seqs)
+        assert rc == 0 and (want_p["status"] == 0).sum() >= 55
+        m.set_guide_producer(sp)
+        got_p, got_b, rc = m.refine_host(seqs)
+        assert rc == 0 and got_p.tobytes() == want_p.tobytes() and got_b.tobytes() == want_b.tobytes()
     finally:
         m.close()
         one.close()
