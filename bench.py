@@ -88,7 +88,7 @@ def host_child(args):
     ref = synth.reference(cfg["ref_len"], synth.REF_SEED, cfg.get("n_frac", 0.0))
     host = synth.generate(n, share_reads=k > 1, ref=ref, **{a: b for a, b in cfg.items() if a != "ref"})
     host = synth.as_windows(synth.compact_blocks(host))
-    pipe = api.HostPipeline(0, depth=args.host_contexts)
+    pipe = api.HostPipeline(0, depth=args.host_contexts, stagger=float(os.environ.get("BENCH_STAGGER", "0.4")))
     pipe.set_scoring(api.make_scoring(band=cfg["band"], max_band=args.max_band, mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR))
     pipe.set_reference(ref)
     bufs = []
