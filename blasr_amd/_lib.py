@@ -91,7 +91,28 @@ class Guides(C.Structure):
                 ("blocks", C.c_void_p), ("blocks_capacity", C.c_uint64), ("blocks_needed", C.c_uint64)]
 
 
-EXPORTS = ("gba_create", "gba_destroy", "gba_set_scoring", "gba_submit", "gba_wait",
+KB_GLOBAL, KB_FIT, KB_EXTEND = 0, 1, 2
+KB_LINEAR, KB_AFFINE_HP = 0, 1
+
+
+class KbandParams(C.Structure):
+    _fields_ = [("sub", (C.c_int32 * 5) * 5), ("ins", C.c_int32), ("dele", C.c_int32),
+                ("align_type", C.c_int32), ("gap_model", C.c_int32),
+                ("hp_ins_open", C.c_int32), ("hp_ins_extend", C.c_int32), ("ins_open", C.c_int32), ("ins_extend", C.c_int32),
+                ("hp_rule", C.c_int32), ("tie_break", C.c_int32), ("max_drops", C.c_int32),
+                ("stats_ins", C.c_int32), ("stats_del", C.c_int32),
+                ("stats_affine", C.c_int32), ("stats_affine_open", C.c_int32), ("stats_affine_extend", C.c_int32)]
+
+
+class KbandBatch(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint32),
+                ("q_arena", C.c_void_p), ("q_off", C.c_void_p), ("q_len", C.c_void_p),
+                ("t_arena", C.c_void_p), ("t_off", C.c_void_p), ("t_len", C.c_void_p),
+                ("q_arena_bytes", C.c_uint64), ("t_arena_bytes", C.c_uint64),
+                ("k", C.c_void_p), ("reverse", C.c_void_p), ("profile", C.c_void_p)]
+
+
+EXPORTS = ("gba_kband", "gba_create", "gba_destroy", "gba_set_scoring", "gba_submit", "gba_wait",
            "gba_submit_device", "gba_submit_device_noalloc", "gba_sdp_device", "gba_sdp", "gba_set_guide_producer", "gba_host_alloc", "gba_host_free", "gba_set_reference", "gba_get_timing", "gba_last_hip_error", "gba_strerror", "gba_version")
 
 _lib = None
@@ -131,6 +152,7 @@ def lib():
         L.gba_sdp.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(SdpParams), C.POINTER(Guides)]
         L.gba_set_guide_producer.argtypes = [C.c_void_p, C.POINTER(SdpParams)]
         L.gba_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.gba_kband.argtypes = [C.c_void_p, C.POINTER(KbandBatch), C.POINTER(KbandParams), C.POINTER(Results)]
         L.gba_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         L.gba_last_hip_error.argtypes = [C.c_void_p]
         L.gba_strerror.argtypes = [C.c_int]

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (BLOCK_DT, PAIR_RESULT_DT, Batch, Config, GbaError, Guides, Results, Scoring, SdpParams, Timing)
+from ._lib import (BLOCK_DT, PAIR_RESULT_DT, Batch, Config, GbaError, Guides, KbandBatch, KbandParams, Results, Scoring, SdpParams, Timing)
 
 
 def make_scoring(match=-5, mismatch=6, n_score=0, ins=5, dele=4, indel=5, band=10, max_band=250,
@@ -213,6 +213,31 @@ class Context:
         rc, needed = self.wait_host()
         return pairs, blocks[:min(needed, int(blocks_capacity))], ops[:min(self.cigar_needed, len(ops))], off, rc
 
+    # ---- fixed-band aligners (KBandAlign, AffineKBandAlign, ExtendAlignmentForward / Reverse)
+    def kband_host(self, batch, params, blocks_capacity=None):
+        """gba_kband on a host batch: dict with q_arena, q_off, q_len, t_arena, t_off, t_len, k (int32 per
+        pair) and optionally reverse (uint8 per pair) and profile (int16, 11 per byte of q_arena).
+        Returns (pairs ndarray[PAIR_RESULT_DT], blocks ndarray[BLOCK_DT], rc)."""
+        n = int(batch["n_pairs"])
+        keep = {k: np.ascontiguousarray(batch[k], dtype=dt) for k, dt in
+                (("q_arena", np.uint8), ("q_off", np.uint64), ("q_len", np.uint32),
+                 ("t_arena", np.uint8), ("t_off", np.uint64), ("t_len", np.uint32), ("k", np.int32))}
+        rev = np.ascontiguousarray(batch["reverse"], dtype=np.uint8) if batch.get("reverse") is not None else None
+        prof = np.ascontiguousarray(batch["profile"], dtype=np.int16) if batch.get("profile") is not None else None
+        if prof is not None and prof.size != keep["q_arena"].size * 11:
+            raise ValueError("profile must hold 11 costs per byte of q_arena")
+        if blocks_capacity is None:
+            blocks_capacity = int(np.minimum(keep["q_len"], keep["t_len"]).astype(np.uint64).sum()) + n
+        b = KbandBatch(n, _ptr(keep["q_arena"]), _ptr(keep["q_off"]), _ptr(keep["q_len"]),
+                       _ptr(keep["t_arena"]), _ptr(keep["t_off"]), _ptr(keep["t_len"]),
+                       keep["q_arena"].size, keep["t_arena"].size, _ptr(keep["k"]),
+                       _ptr(rev) if rev is not None else None, _ptr(prof) if prof is not None else None)
+        pairs = np.zeros(n, dtype=PAIR_RESULT_DT)
+        blocks = np.zeros(max(int(blocks_capacity), 1), dtype=BLOCK_DT)
+        r = Results(_ptr(pairs), _ptr(blocks), int(blocks_capacity), 0, None, None, 0, 0, 0)
+        rc = self._check(self._L.gba_kband(self._h, C.byref(b), C.byref(params), C.byref(r)), allow=(_lib.E_NOSPACE,))
+        return pairs, blocks[:min(int(r.blocks_needed), int(blocks_capacity))], rc
+
     # ---- guide production
     def sdp_host(self, batch, params, blocks_capacity=None):
         """gba_sdp on a host batch (numpy arrays; its guide entries are not read).  Returns
@@ -295,6 +320,29 @@ class Context:
         rc = self._check(fn(self._h, C.byref(b), C.byref(r)), allow=(_lib.E_NOSPACE,))
         self.cigar_needed = int(r.cigar_needed)
         return rc, int(r.blocks_needed)
+
+
+def make_kband_params(align_type=_lib.KB_GLOBAL, gap_model=_lib.KB_LINEAR, match=-5, mismatch=6, n_score=0, ins=5, dele=5,
+                      indel=5, sub=None, hp_rule=0, tie_break=_lib.TIE_DIAG_LEFT_UP, max_drops=10,
+                      hp_ins_open=None, hp_ins_extend=None, ins_open=None, ins_extend=None,
+                      stats_affine=0, stats_affine_open=0, stats_affine_extend=0):
+    """gba_kband_params.  The affine costs default to what PairwiseLocalAlign passes
+    (iblasr/BlasrAlignImpl.hpp:1259-1262): homopolymer insertion indel + 2 / indel - 3, any insertion
+    indel + 2 / indel - 1, deletion indel; max_drops to params.maxExtendDropoff
+    (iblasr/MappingParameters.h:288); rescoring with (indel, indel)."""
+    p = KbandParams()
+    for a in range(5):
+        for b in range(5):
+            p.sub[a][b] = int(sub[a][b]) if sub is not None else (n_score if a == 4 or b == 4 else (match if a == b else mismatch))
+    p.ins, p.dele, p.align_type, p.gap_model = ins, dele, align_type, gap_model
+    p.hp_ins_open = indel + 2 if hp_ins_open is None else hp_ins_open
+    p.hp_ins_extend = indel - 3 if hp_ins_extend is None else hp_ins_extend
+    p.ins_open = indel + 2 if ins_open is None else ins_open
+    p.ins_extend = indel - 1 if ins_extend is None else ins_extend
+    p.hp_rule, p.tie_break, p.max_drops = hp_rule, tie_break, max_drops
+    p.stats_ins, p.stats_del = indel, indel
+    p.stats_affine, p.stats_affine_open, p.stats_affine_extend = stats_affine, stats_affine_open, stats_affine_extend
+    return p
 
 
 def make_sdp_params(tuple_size=11, ins=5, dele=10, match=5, max_fragments=1024):

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(_HERE)
 LIBGBA = os.path.join(_HERE, "libgba.so")
 SRC = os.path.join(_HERE, "csrc", "gba.hip")
 HDR = os.path.join(ROOT, "include", "gba.h")
+INC = os.path.join(_HERE, "csrc", "gba_kband.inc")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-Wall", "-Wno-unused-function"]
@@ -23,10 +24,10 @@ ISA = os.path.join(_HERE, "csrc", "gba_gfx950.s")      # device assembly of the 
 
 
 def build_libgba(force=False, extra=()):
-    if force or _stale(LIBGBA, [SRC, HDR]):
+    if force or _stale(LIBGBA, [SRC, HDR, INC]):
         cmd = ["hipcc"] + HIPCC_FLAGS + list(extra) + ["-o", LIBGBA, SRC]
         subprocess.check_call(cmd)
-    if force or _stale(ISA, [SRC, HDR]):
+    if force or _stale(ISA, [SRC, HDR, INC]):
         flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
         subprocess.check_call(["hipcc"] + flags + list(extra) + ["-S", "--cuda-device-only", "-o", ISA, SRC])
     return LIBGBA

@@ -2083,6 +2083,10 @@ __global__ __launch_bounds__(256) void k_sdp_emit(const gba_block *chains, uint3
     for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) out[o + i] = src[i];
 }
 
+#define GBA_KBAND_KERNELS
+#include "gba_kband.inc"
+#undef GBA_KBAND_KERNELS
+
 // ================================================================ host side
 struct Buf {
     void *ptr = nullptr;
@@ -2158,6 +2162,7 @@ struct gba_ctx {
     Slot slot[NSLOT];
     // host-buffer batches: device copies of the caller's batch, the copy streams, the worker thread
     Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res, s_cigoff, s_gout;
+    Buf kb[9];                       // gba_kband: band widths, strand flags, cost profile, arrow offsets, matrix, arrows, block slots, counts, offsets
     hipStream_t s_in = nullptr, s_out = nullptr;     // host-to-device and device-to-host copies, beside the kernels
     std::vector<hipEvent_t> ev_in;                   // per part: its inputs have arrived
     std::vector<hipEvent_t> ev_sdp;                  // per part of the guide producer: its sequences have arrived
@@ -2905,6 +2910,7 @@ void gba_destroy(gba_ctx *c)
                  &c->s_q, &c->s_t, &c->s_blk, &c->s_qoff, &c->s_toff, &c->s_boff, &c->s_qlen, &c->s_tlen,
                  &c->s_nblk, &c->s_res, &c->s_cigoff, &c->s_gout};
     for (Buf *b : bs) release(*b);
+    for (auto &b : c->kb) release(b);
     if (c->h_needed) (void)hipHostFree(c->h_needed);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (int h = 0; h < NSLOT; h++) {
@@ -3290,3 +3296,7 @@ int gba_get_timing(gba_ctx *c, gba_timing *t)
 }
 
 }  // extern "C"
+
+#define GBA_KBAND_HOST
+#include "gba_kband.inc"
+#undef GBA_KBAND_HOST

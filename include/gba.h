@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GBA_VERSION 340   /* major*10000 + minor*100 + patch */
+#define GBA_VERSION 350   /* major*10000 + minor*100 + patch */
 
 /* return codes of the entry points */
 enum {
@@ -305,6 +305,65 @@ int gba_set_guide_producer(gba_ctx *ctx, const gba_sdp_params *params);
  * memory for batches whose t_arena is NULL; len == 0 drops it.  Replaces the
  * per-candidate window copies out of the genome, iblasr/BlasrAlignImpl.hpp:727-743. */
 int gba_set_reference(gba_ctx *ctx, const uint8_t *ref, uint64_t len);
+
+/* ---- fixed-band aligners: the other pairwise aligners of the refine stage --------------------
+ * One entry point for the reference's fixed-band family, which the guided path falls back to or
+ * is followed by:
+ *   KBandAlign(qSeq, tSeq, SMRTDistanceMatrix, ins, del, k, scoreMat, pathMat, alignment, scoreFn, alignType)
+ *     iblasr/BlasrUtilsImpl.hpp:657-661 (-global: Global, k = drift) and
+ *     iblasr/BlasrAlignImpl.hpp:1278-1294 (quality-value scorers, Fit: the legacy refine of
+ *     iblasr/BlasrUtilsImpl.hpp:775-902)                       -> GBA_KB_GLOBAL / GBA_KB_FIT, GBA_KB_LINEAR
+ *   AffineKBandAlign(qSeq, tSeq, SMRTDistanceMatrix, hpInsOpen, hpInsExtend, insOpen, insExtend, del, k, ...)
+ *     iblasr/BlasrAlignImpl.hpp:1259-1267                         -> GBA_KB_GLOBAL, GBA_KB_AFFINE_HP
+ *   ExtendAlignmentForward(readSuffix, 0, genomeSuffix, 0, extendBandSize, ..., distScoreFn, 1, maxExtendDropoff)
+ *     iblasr/BlasrAlignImpl.hpp:1086-1099, ExtendAlignmentReverse :1144-1155 (-extend)
+ *                                                                 -> GBA_KB_EXTEND (reverse[p] for the prefix side)
+ * Cells (i, j) with |j - i| <= k[p]; lower scores are better.  FIT: the whole query against a part of
+ * the target (row 0 is free, the end is the cheapest cell of the last row, the leftmost on ties).
+ * EXTEND: from (0, 0); rows are taken in order, the fill ends with the (max_drops + 1)-th row in a row
+ * that brought no new minimum, the alignment ends in the best cell ((0, 0): nothing is extended, no
+ * blocks, score 0; the caller extends when the score is negative, BlasrAlignImpl.hpp:1102).
+ * AFFINE_HP: the match state keeps linear deletions; an insertion run costs ins_open for its first base
+ * and ins_extend for each further one; a homopolymer insertion (hp_ins_open / hp_ins_extend) is allowed
+ * where the inserted base equals the target base to its left (hp_rule 0) or the query base before it
+ * (hp_rule 1).  These routines are libcpp code absent from the reference tree: every such choice is a
+ * field here.
+ * Quality-value scorers (IDSScoreFunction, QualityValueScoreFunction: iblasr/BlasrUtilsImpl.hpp:636-646,
+ * iblasr/BlasrAlignImpl.hpp:1241-1253) come in as a cost profile: for the query base at arena byte x,
+ * profile[11 x .. 11 x + 10] = Match cost against target code A, C, G, T, N; Insertion cost of the
+ * base; Deletion cost of a target base of code A, C, G, T, N skipped after this base.  Row 0 uses del.
+ * Limits: k <= 255 (GBA_PAIR_TOO_WIDE), q_len + t_len < 2^19 and, for EXTEND, q_len <= 4095
+ * (GBA_PAIR_TOO_LONG), |cost| <= 1023 (GBA_E_UNSUPPORTED).  GLOBAL needs |t_len - q_len| <= k, FIT
+ * q_len - t_len <= k (GBA_PAIR_END_OUT_OF_BAND).  reverse[p] != 0: both sequences are read back to front; blocks and
+ * positions are reported in forward coordinates.  Results as for gba_submit: q_pos / t_pos = start of the
+ * first block, blocks relative to it; ncells = band cells of the rows filled.  Host pointers; returns when
+ * the results are in `host_out` (GBA_E_NOSPACE as for gba_wait); CIGAR output is not offered here. */
+enum { GBA_KB_GLOBAL = 0, GBA_KB_FIT = 1, GBA_KB_EXTEND = 2 };
+enum { GBA_KB_LINEAR = 0, GBA_KB_AFFINE_HP = 1 };
+
+typedef struct {
+    int32_t sub[5][5];
+    int32_t ins, del;
+    int32_t align_type, gap_model;
+    int32_t hp_ins_open, hp_ins_extend, ins_open, ins_extend;
+    int32_t hp_rule;
+    int32_t tie_break;          /* GBA_TIE_*; the two insertion states rank where Up does */
+    int32_t max_drops;          /* EXTEND: params.maxExtendDropoff (10, iblasr/MappingParameters.h:288) */
+    int32_t stats_ins, stats_del;                                     /* rescoring of the path, as gba_scoring's */
+    int32_t stats_affine, stats_affine_open, stats_affine_extend;
+} gba_kband_params;
+
+typedef struct {
+    uint32_t n_pairs;
+    const uint8_t *q_arena; const uint64_t *q_off; const uint32_t *q_len;
+    const uint8_t *t_arena; const uint64_t *t_off; const uint32_t *t_len;
+    uint64_t q_arena_bytes, t_arena_bytes;
+    const int32_t *k;           /* per pair: half-width of the band */
+    const uint8_t *reverse;     /* per pair, may be NULL */
+    const int16_t *profile;     /* NULL: matrix, ins, del; else 11 costs per byte of q_arena */
+} gba_kband_batch;
+
+int gba_kband(gba_ctx *ctx, const gba_kband_batch *host_batch, const gba_kband_params *params, gba_results *host_out);
 
 int gba_get_timing(gba_ctx *ctx, gba_timing *t);
 int gba_last_hip_error(gba_ctx *ctx);

@@ -52,7 +52,7 @@ RESULT_DT = np.dtype([
 
 def build(force=False):
     if force or not os.path.exists(_SO) or \
-            os.path.getmtime(_SO) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("gba_oracle.c", "sdp_oracle.c")):
+            os.path.getmtime(_SO) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("gba_oracle.c", "sdp_oracle.c", "kband_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -71,6 +71,8 @@ def lib():
         _lib.gbo_full_dp_score.restype = C.c_int
         _lib.gbo_align_batch.restype = C.c_int
         _lib.gbo_align_batch_mt.restype = C.c_int
+        _lib.kbo_align.restype = C.c_int
+        _lib.kbo_full_dp.restype = C.c_int
         _lib.sdo_chain.restype = C.c_int
         _lib.sdo_chain_batch.restype = C.c_int
     return _lib
@@ -258,3 +260,42 @@ def sdp_chain_batch(batch, params, first=0, count=None):
                           p(status), p(n_blk), p(score), p(n_frag), p(out), p(out_off), p(caps))
     blks = [out[i * mf:i * mf + int(n_blk[i])].copy() for i in range(count)]
     return status, n_blk, score, n_frag, blks
+
+
+# ---- fixed-band aligners (kband_oracle.c)
+KB_GLOBAL, KB_FIT, KB_EXTEND = 0, 1, 2
+KB_LINEAR, KB_AFFINE_HP = 0, 1
+
+
+class KbandParams(C.Structure):
+    _fields_ = [("sub", (C.c_int32 * 5) * 5), ("ins", C.c_int32), ("dele", C.c_int32),
+                ("align_type", C.c_int32), ("gap_model", C.c_int32),
+                ("hp_ins_open", C.c_int32), ("hp_ins_extend", C.c_int32), ("ins_open", C.c_int32), ("ins_extend", C.c_int32),
+                ("hp_rule", C.c_int32), ("tie_break", C.c_int32), ("max_drops", C.c_int32),
+                ("stats_ins", C.c_int32), ("stats_del", C.c_int32),
+                ("stats_affine", C.c_int32), ("stats_affine_open", C.c_int32), ("stats_affine_extend", C.c_int32)]
+
+
+def kband_align(q, t, k, params, profile=None, reverse=False, blk_cap=None):
+    """One pair through kbo_align.  `params` is any ctypes structure with the layout of KbandParams
+    (the library's own gba_kband_params has it).  profile: int16[len(q) * 11] or None.
+    Returns (result dict, blocks ndarray[BLOCK_DT])."""
+    q, t = _u8(q), _u8(t)
+    cap = int(blk_cap if blk_cap is not None else min(len(q), len(t)) + 1)
+    out = np.zeros(max(cap, 1), dtype=BLOCK_DT)
+    res = Result()
+    prof = np.ascontiguousarray(profile, dtype=np.int16) if profile is not None else None
+    lib().kbo_align(q.ctypes.data_as(C.c_void_p), C.c_uint32(len(q)), t.ctypes.data_as(C.c_void_p), C.c_uint32(len(t)),
+                    C.c_int32(int(k)), C.c_int32(1 if reverse else 0), C.byref(params),
+                    prof.ctypes.data_as(C.c_void_p) if prof is not None else None,
+                    out.ctypes.data_as(C.c_void_p), C.c_uint32(cap), C.byref(res))
+    d = {f[0]: getattr(res, f[0]) for f in Result._fields_}
+    return d, out[:min(d["n_blk"], cap)].copy()
+
+
+def kband_full_dp(q, t, params):
+    q, t = _u8(q), _u8(t)
+    s = C.c_int32(0)
+    lib().kbo_full_dp(q.ctypes.data_as(C.c_void_p), C.c_uint32(len(q)), t.ctypes.data_as(C.c_void_p), C.c_uint32(len(t)),
+                      C.byref(params), C.byref(s))
+    return s.value
