@@ -330,7 +330,10 @@ def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: Mappi
             cands.sort(key=lambda c: c.score)
         return cands
     if not params.useGuidedAlign:
-        raise NotImplementedError("the legacy -noUseGuidedAlign branch (:775-902) is not on the accelerated path")
+        refine_legacy(read, cands, params, ctx)
+        if params.sortRefinedAlignments:
+            cands.sort(key=lambda c: c.score)
+        return cands
     ctx.set_scoring(scoring_from_params(params))
     batch = build_batch(read, cands)
     if want_blocks:
@@ -403,3 +406,324 @@ def RemoveLowQualityAlignments(cands: List[AlignmentCandidate], params: MappingP
             del cands[i:]
             break
     return cands
+
+
+# ------------------------------------------------------------------------------------------------
+# The fixed-band aligners around the guided path (gba_kband): quality-value scorers, the -global
+# branch with them, the legacy k-band refine, and the end extension of -extend.
+
+@dataclass
+class QualityValues:
+    """The per-base fields of a FASTQSequence / SMRTSequence that the QV-aware scorers read
+    (bytes or uint8 arrays as long as the read; None = absent, like an Empty() QV vector)."""
+    qual: Optional[bytes] = None
+    insertionQV: Optional[bytes] = None
+    deletionQV: Optional[bytes] = None
+    deletionTag: Optional[bytes] = None
+    substitutionQV: Optional[bytes] = None
+    substitutionTag: Optional[bytes] = None
+
+
+_ACGTN = b"ACGTN"
+_CODE = np.full(256, 4, np.int64)
+for _i, _c in enumerate(b"ACGT"):
+    _CODE[_c] = _i
+    _CODE[_c + 32] = _i
+
+
+def _matrix(p: MappingParameters):
+    if p.scoreMatrix is not None:
+        return np.asarray(p.scoreMatrix, np.int64)
+    m = np.full((5, 5), p.mismatch, np.int64)
+    m[np.arange(4), np.arange(4)] = p.match
+    m[4, :] = 0
+    m[:, 4] = 0
+    return m
+
+
+def ids_profile(read: bytes, qv: QualityValues, p: MappingParameters, substitutionPrior: int = 20, globalDeletionPrior: int = 13):
+    """IDSScoreFunction<DNASequence, FASTQSequence> as RefineAlignment sets it up
+    (/root/reference/iblasr/BlasrUtilsImpl.hpp:636-646: ins = params.insertion, del = params.deletion,
+    substitutionPrior, globalDeletionPrior, InitializeScoreMatrix(SMRTDistanceMatrix); defaults
+    iblasr/MappingParameters.h:350-351), evaluated for every query base into the cost profile gba_kband
+    takes.  The class is libcpp code and not in the reference tree; UNPINNED, restated as
+      Match(t, q_i)     = matrix[q_i][q_i] when the bases agree; substitutionQV[i] when the target base is
+                          the read's substitutionTag[i]; substitutionPrior otherwise;
+      Insertion(q_i)    = insertionQV[i] (ins without insertion QVs);
+      Deletion(t, q_i)  = deletionQV[i] when the target base is the read's deletionTag[i];
+                          globalDeletionPrior otherwise (del without deletion QVs / tags).
+    Every value is clamped to the +-1023 the kernels take."""
+    n = len(read)
+    q = np.frombuffer(read, np.uint8)
+    qc = _CODE[q]
+    m = _matrix(p)
+    prof = np.zeros((n, 11), np.int64)
+    arr = lambda b: np.frombuffer(b, np.uint8).astype(np.int64) if b is not None else None
+    sq, st = arr(qv.substitutionQV), arr(qv.substitutionTag)
+    iq, dq, dt = arr(qv.insertionQV), arr(qv.deletionQV), arr(qv.deletionTag)
+    for c in range(5):
+        col = np.full(n, substitutionPrior, np.int64)
+        if sq is not None and st is not None:
+            col = np.where(_CODE[st] == c, sq, col) if c < 4 else col
+        col = np.where(qc == c, m[qc, qc], col)
+        prof[:, c] = col
+        if dq is not None and dt is not None:
+            prof[:, 6 + c] = np.where((_CODE[dt] == c) & (dt != ord("N")), dq, globalDeletionPrior) if c < 4 else globalDeletionPrior
+        else:
+            prof[:, 6 + c] = p.deletion
+    prof[:, 5] = iq if iq is not None else p.insertion
+    return np.clip(prof, -1023, 1023).astype(np.int16).reshape(-1)
+
+
+def qv_profile(read: bytes, qv: QualityValues, p: MappingParameters):
+    """QualityValueScoreFunction with ins = del = params.indel (:639-640; BlasrAlignImpl.hpp:1241-1243):
+    UNPINNED, restated as Match = 0 for equal bases and the base's quality value otherwise, constant gaps."""
+    n = len(read)
+    qc = _CODE[np.frombuffer(read, np.uint8)]
+    qual = np.frombuffer(qv.qual, np.uint8).astype(np.int64) if qv.qual is not None else np.full(n, p.mismatch, np.int64)
+    prof = np.zeros((n, 11), np.int64)
+    for c in range(5):
+        prof[:, c] = np.where(qc == c, 0, qual)
+    prof[:, 5] = p.indel
+    prof[:, 6:] = p.indel
+    return np.clip(prof, -1023, 1023).astype(np.int16).reshape(-1)
+
+
+def ReadHasMeaningfulQualityValues(qv: Optional[QualityValues]):
+    """The test PairwiseLocalAlign makes before it trusts quality values (BlasrAlignImpl.hpp:1257): some
+    quality value of the read differs from 0."""
+    return qv is not None and qv.qual is not None and bool(np.frombuffer(qv.qual, np.uint8).any())
+
+
+def _kband_params(p: MappingParameters, align_type, gap_model=_lib.KB_LINEAR, ins=None, dele=None, max_drops=10):
+    from .api import make_kband_params
+    return make_kband_params(align_type=align_type, gap_model=gap_model, ins=p.insertion if ins is None else ins,
+                             dele=p.deletion if dele is None else dele, indel=p.indel, sub=_matrix(p).tolist(),
+                             tie_break=p.tieBreak, max_drops=max_drops)
+
+
+def _kband_batch(seq_pairs, ks, profile_parts=None, reverse=None):
+    n = len(seq_pairs)
+    q_len = np.array([len(q) for q, _ in seq_pairs], np.uint32)
+    t_len = np.array([len(t) for _, t in seq_pairs], np.uint32)
+    q_off = np.zeros(n, np.uint64); t_off = np.zeros(n, np.uint64)
+    q_off[1:] = np.cumsum(q_len[:-1].astype(np.uint64)); t_off[1:] = np.cumsum(t_len[:-1].astype(np.uint64))
+    b = {"n_pairs": n, "q_arena": np.frombuffer(b"".join(bytes(q) for q, _ in seq_pairs) or b"N", np.uint8),
+         "t_arena": np.frombuffer(b"".join(bytes(t) for _, t in seq_pairs) or b"N", np.uint8),
+         "q_off": q_off, "t_off": t_off, "q_len": q_len, "t_len": t_len, "k": np.asarray(ks, np.int32)}
+    if profile_parts is not None:
+        prof = np.concatenate(profile_parts) if sum(len(x) for x in profile_parts) else np.zeros(11, np.int16)
+        b["profile"] = np.ascontiguousarray(prof, np.int16) if len(prof) == len(b["q_arena"]) * 11 else np.zeros(len(b["q_arena"]) * 11, np.int16)
+    if reverse is not None:
+        b["reverse"] = np.asarray(reverse, np.uint8)
+    return b
+
+
+def _stats_into(c: AlignmentCandidate, r):
+    c.nMatch, c.nMismatch, c.nIns, c.nDel = int(r["n_match"]), int(r["n_mismatch"]), int(r["n_ins"]), int(r["n_del"])
+    cols = c.nMatch + c.nMismatch + c.nIns + c.nDel
+    c.pctSimilarity = (c.nMatch * 2.0) / (2 * cols) * 100.0 if cols else 0.0
+    c.score, c.nCells = int(r["score"]), int(r["ncells"])
+
+
+def PairwiseLocalAlign(seq_pairs, ks, params: MappingParameters, ctx, alignType=_lib.KB_FIT, qvs=None):
+    """PairwiseLocalAlign(qSeq, tSeq, k, params, alignment, mappingBuffers, alignType)
+    (/root/reference/iblasr/BlasrAlignImpl.hpp:1226-1309) for a list of (query, target) pairs in one call.
+    Without usable quality values: AffineKBandAlign(qSeq, tSeq, SMRTDistanceMatrix, indel+2, indel-3,
+    indel+2, indel-1, indel, k*1.2, ..., Global) (:1259-1267).  With them: KBandAlign(..., indel+2, indel+2,
+    k, ..., idsScoreFn or scoreFn, alignType) (:1278-1294; the IDS scorer when the read has insertion
+    QVs).  Then ComputeAlignmentStats with distScoreFn2 (:1304).  qvs: one QualityValues (or None) per
+    pair.  Returns (pair results, blocks)."""
+    n = len(seq_pairs)
+    qvs = qvs if qvs is not None else [None] * n
+    plain = [i for i in range(n) if not ReadHasMeaningfulQualityValues(qvs[i])]
+    withqv = [i for i in range(n) if ReadHasMeaningfulQualityValues(qvs[i])]
+    pairs_out = np.zeros(n, dtype=_lib.PAIR_RESULT_DT)
+    blocks_out = [np.zeros(0, BLOCK_DT)] * n
+
+    def run(idx, P, ks_, profile_parts=None):
+        if not idx:
+            return
+        b = _kband_batch([seq_pairs[i] for i in idx], ks_, profile_parts)
+        pr, bl, rc = ctx.kband_host(b, P)
+        for x, i in enumerate(idx):
+            pairs_out[i] = pr[x]
+            blocks_out[i] = bl[int(pr[x]["blk_off"]):int(pr[x]["blk_off"]) + int(pr[x]["n_blk"])].copy() if int(pr[x]["status"]) == 0 else np.zeros(0, BLOCK_DT)
+
+    run(plain, _kband_params(params, _lib.KB_GLOBAL, _lib.KB_AFFINE_HP, ins=params.indel, dele=params.indel),
+        [int(ks[i] * 1.2) for i in plain])
+    if withqv:
+        Pq = _kband_params(params, alignType, ins=params.indel + 2, dele=params.indel + 2)
+        run(withqv, Pq, [int(ks[i]) for i in withqv],
+            [ids_profile(bytes(seq_pairs[i][0]), qvs[i], params) if qvs[i].insertionQV is not None
+             else qv_profile(bytes(seq_pairs[i][0]), qvs[i], params) for i in withqv])
+    return pairs_out, blocks_out
+
+
+def refine_legacy(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx, qv: Optional[QualityValues] = None):
+    """The branch of RefineAlignment without guided alignment (-noUseGuidedAlign,
+    /root/reference/iblasr/BlasrUtilsImpl.hpp:775-902): the two sequences are cut to the span of the SDP
+    blocks, k = params.bandSize or |drift| * 1.5, at least 10 (:848-861), the positions move into the
+    aligned-sequence offsets (:863-887), and PairwiseLocalAlign(qSeq, tSeq, k, ..., Fit) aligns them
+    afresh (:901).  A candidate without blocks gets score 0 (:800-803)."""
+    todo, seqs, ks = [], [], []
+    for c in cands:
+        if len(c.blocks) == 0:
+            c.score = 0
+            continue
+        last = c.blocks[len(c.blocks) - 1]
+        ql = int(last["q_pos"]) + int(last["length"])                     # qIsSubstring form (:826-830)
+        tl = int(last["t_pos"]) + int(last["length"]) - int(c.blocks[0]["t_pos"])
+        qs = c.qPos + c.qAlignedSeqPos
+        k = params.bandSize if params.bandSize else int(abs(compute_drift(c.blocks)) * 1.5)
+        k = max(k, 10)
+        seqs.append((read[qs:qs + ql], c.tAlignedSeq[c.tPos:c.tPos + tl])); ks.append(k); todo.append(c)
+        c.tAlignedSeqPos += c.tPos
+        c.tAlignedSeqLength = tl
+        c.qAlignedSeqPos += c.qPos
+        c.qAlignedSeqLength = int(last["q_pos"]) + int(last["length"]) - int(c.blocks[0]["q_pos"])
+        c.tPos = c.qPos = 0
+        c.tAlignedSeq, c.qAlignedSeq = seqs[-1][1], seqs[-1][0]
+    if not todo:
+        return cands
+    qvs = None
+    if qv is not None:
+        cut = lambda b, s, l: b[s:s + l] if b is not None else None
+        qvs = []
+        for c, (qs_, _) in zip(todo, seqs):
+            s, l = c.qAlignedSeqPos, len(qs_)
+            qvs.append(QualityValues(*[cut(getattr(qv, f), s, l) for f in
+                                       ("qual", "insertionQV", "deletionQV", "deletionTag", "substitutionQV", "substitutionTag")]))
+    pairs, blocks = PairwiseLocalAlign(seqs, ks, params, ctx, _lib.KB_FIT, qvs)
+    for c, r, b in zip(todo, pairs, blocks):
+        c.status = int(r["status"])
+        c.blocks = b
+        c.nBlocks = len(b)
+        if c.status != _lib.PAIR_OK:
+            continue
+        c.qPos, c.tPos = int(r["q_pos"]), int(r["t_pos"])
+        _stats_into(c, r)
+        c.qInterval = (c.qAlignedSeqPos + int(r["q_start"]), c.qAlignedSeqPos + int(r["q_end"]))
+        c.tInterval = (c.tAlignedSeqPos + int(r["t_start"]), c.tAlignedSeqPos + int(r["t_end"]))
+    return cands
+
+
+def refine_global_qv(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx, qv: QualityValues,
+                     subread_start: int = 0, subread_length: Optional[int] = None):
+    """The -global branch (:648-675) as written, with the IDS scorer on the read's quality values:
+    KBandAlign(subread, tAlignedSeq, SMRTDistanceMatrix, params.insertion, params.deletion, drift, ...,
+    idsScoreFn, Global), RemoveEndGaps, ComputeAlignmentStats with distScoreFn2.  One call for all
+    candidates (the band is per pair)."""
+    if subread_length is None:
+        subread_length = len(read) - subread_start
+    sub = read[subread_start:subread_start + subread_length]
+    cut = lambda b: b[subread_start:subread_start + subread_length] if b is not None else None
+    prof = ids_profile(sub, QualityValues(*[cut(getattr(qv, f)) for f in
+                                            ("qual", "insertionQV", "deletionQV", "deletionTag", "substitutionQV", "substitutionTag")]), params)
+    if not cands:
+        return cands
+    seqs = [(sub, c.tAlignedSeq) for c in cands]
+    ks = [compute_drift(c.blocks) for c in cands]
+    b = _kband_batch(seqs, ks, [prof] * len(cands))
+    pairs, blocks, rc = ctx.kband_host(b, _kband_params(params, _lib.KB_GLOBAL))
+    for c, r in zip(cands, pairs):
+        c.status = int(r["status"])
+        if c.status != _lib.PAIR_OK:
+            continue
+        c.blocks = blocks[int(r["blk_off"]):int(r["blk_off"]) + int(r["n_blk"])].copy()
+        c.tPos, c.qPos = int(r["t_pos"]), int(r["q_pos"]) + subread_start       # blocks already start at their first block
+        c.score = int(r["score"])
+    return cands
+
+
+_COMP = bytes.maketrans(b"ACGTacgtNn", b"TGCAtgcaNn")
+
+
+def _genome_slice(genome: bytes, pos: int, length: int, strand: int):
+    """genome.Copy(pos, length) on the forward strand, CopyAsRC / MakeRC on the reverse strand, where
+    positions count along the reverse complement (BlasrAlignImpl.hpp:1074-1079, :1135-1140)."""
+    if strand == 0:
+        return genome[pos:pos + length]
+    g = len(genome)
+    return genome[g - pos - length:g - pos].translate(_COMP)[::-1]
+
+
+MAXIMUM_EXTEND_LENGTH = 500      # BlasrAlignImpl.hpp:1039
+
+
+def ExtendAlignments(read: bytes, cands: List[AlignmentCandidate], genome: bytes, params: MappingParameters, ctx,
+                     extendBandSize: int = 10, maxExtendDropoff: int = 10, contigStart: int = 0, contigEnd: Optional[int] = None):
+    """The -extend step of AlignIntervals (/root/reference/iblasr/BlasrAlignImpl.hpp:1011-1201) for all
+    candidates of a read in one call: behind the last block up to 500 bases of read and genome go
+    through ExtendAlignmentForward (:1086-1099), in front of the first block up to 500 through
+    ExtendAlignmentReverse (:1144-1155), both with distScoreFn, extendBandSize and maxExtendDropoff; an
+    extension with a negative score is spliced on (:1102-1120, :1158-1196).  Positions of a
+    reverse-strand candidate count along the reverse complement of the genome, as the reference's do.
+    Counts and score of the pieces add up (ComputeAlignmentStats with distScoreFn2 at :1214 rescans
+    the whole alignment; with its linear gap costs that is the sum).  Returns the number of ends extended."""
+    contigEnd = len(genome) if contigEnd is None else contigEnd
+    jobs, seqs, rev = [], [], []
+    for ci, c in enumerate(cands):
+        if len(c.blocks) == 0:
+            continue
+        last = c.blocks[len(c.blocks) - 1]
+        lastQ = int(last["q_pos"]) + int(last["length"]) + c.qPos + c.qAlignedSeqPos
+        lastT = int(last["t_pos"]) + int(last["length"]) + c.tPos + c.tAlignedSeqPos
+        rl = min(len(read) - lastQ, MAXIMUM_EXTEND_LENGTH)
+        gl = min(contigEnd - lastT, MAXIMUM_EXTEND_LENGTH)
+        if rl > 0 and gl > 0:
+            jobs.append((ci, 0, lastQ, lastT, rl, gl)); rev.append(0)
+            seqs.append((read[lastQ:lastQ + rl], _genome_slice(genome, lastT, gl, c.tStrand)))
+        firstQ, firstT = c.qPos + c.qAlignedSeqPos, c.tPos + c.tAlignedSeqPos
+        rl = min(firstQ, MAXIMUM_EXTEND_LENGTH)
+        gl = min(firstT - contigStart, MAXIMUM_EXTEND_LENGTH)
+        if rl > 0 and gl > 0:
+            jobs.append((ci, 1, firstQ - rl, firstT - gl, rl, gl)); rev.append(1)
+            seqs.append((read[firstQ - rl:firstQ], _genome_slice(genome, firstT - gl, gl, c.tStrand)))
+    if not jobs:
+        return 0
+    # AlignIntervals' own distScoreFn(SMRTDistanceMatrix, params.insertion, params.deletion) (BlasrAlignImpl.hpp:576), read as ctor(ins, del)
+    P = _kband_params(params, _lib.KB_EXTEND, ins=params.insertion, dele=params.deletion, max_drops=maxExtendDropoff)
+    pairs, blocks, rc = ctx.kband_host(_kband_batch(seqs, [extendBandSize] * len(jobs), reverse=rev), P)
+    done = 0
+    # forward extensions first, then the reverse ones, as the reference does per candidate
+    for order in (0, 1):
+        for (ci, side, q0, t0, rl, gl), r, (qs, ts) in zip(jobs, pairs, seqs):
+            if side != order or int(r["status"]) != _lib.PAIR_OK or int(r["dp_score"]) >= 0 or int(r["n_blk"]) == 0:
+                continue
+            c = cands[ci]
+            eb = blocks[int(r["blk_off"]):int(r["blk_off"]) + int(r["n_blk"])]
+            eq, et = int(r["q_pos"]), int(r["t_pos"])
+            qend, tend = eq + int(eb[-1]["q_pos"]) + int(eb[-1]["length"]), et + int(eb[-1]["t_pos"]) + int(eb[-1]["length"])
+            oq, ot = c.qPos + c.qAlignedSeqPos, c.tPos + c.tAlignedSeqPos      # origin of the candidate's blocks
+            if side == 0:
+                nb = eb.copy()
+                nb["q_pos"] += np.uint32(q0 + eq - oq); nb["t_pos"] += np.uint32(t0 + et - ot)
+                c.blocks = np.concatenate([c.blocks, nb])
+                c.tAlignedSeq = c.tAlignedSeq + ts[:tend]
+                c.qAlignedSeqLength = (c.qAlignedSeqLength or len(c.qAlignedSeq)) + qend
+                c.qAlignedSeq = read[c.qAlignedSeqPos:c.qAlignedSeqPos + c.qAlignedSeqLength]
+                c.tAlignedSeqLength = len(c.tAlignedSeq)
+            else:
+                ob = c.blocks.copy()
+                ob["q_pos"] += np.uint32(oq - (q0 + eq)); ob["t_pos"] += np.uint32(ot - (t0 + et))
+                c.blocks = np.concatenate([eb, ob])
+                c.tAlignedSeq = ts[:gl - c.tPos] + c.tAlignedSeq
+                old_qlen = c.qAlignedSeqLength or len(c.qAlignedSeq)
+                c.tAlignedSeqPos, c.qAlignedSeqPos = t0, q0
+                c.tPos, c.qPos = et, eq
+                c.qAlignedSeqLength = rl + old_qlen
+                c.qAlignedSeq = read[q0:q0 + c.qAlignedSeqLength]
+                c.tAlignedSeqLength = len(c.tAlignedSeq)
+            c.nBlocks = len(c.blocks)
+            c.nMatch += int(r["n_match"]); c.nMismatch += int(r["n_mismatch"])
+            c.nIns += int(r["n_ins"]); c.nDel += int(r["n_del"])
+            c.score += int(r["score"])
+            cols = c.nMatch + c.nMismatch + c.nIns + c.nDel
+            c.pctSimilarity = (c.nMatch * 2.0) / (2 * cols) * 100.0 if cols else 0.0
+            first, lastb = c.blocks[0], c.blocks[-1]
+            base_q, base_t = c.qPos + c.qAlignedSeqPos, c.tPos + c.tAlignedSeqPos
+            c.qInterval = (base_q + int(first["q_pos"]), base_q + int(lastb["q_pos"]) + int(lastb["length"]))
+            c.tInterval = (base_t + int(first["t_pos"]), base_t + int(lastb["t_pos"]) + int(lastb["length"]))
+            done += 1
+    return done
