@@ -436,6 +436,203 @@ inline int RefineGlobal(const std::string &read, std::vector<AlignmentCandidate 
     return GBA_OK;
 }
 
+// ---- the fixed-band aligners beside the guided path (gba_kband) ----------------------------------
+// gba_kband_params from MappingParameters: SMRTDistanceMatrix, the two gap costs given, rescoring with
+// distScoreFn2 (indel, indel); the affine costs are the ones PairwiseLocalAlign passes to AffineKBandAlign
+// (/root/reference/iblasr/BlasrAlignImpl.hpp:1259-1262).
+inline gba_kband_params KBandParams(const MappingParameters &p, int alignType, int gapModel, int ins, int del, int maxDrops = 10)
+{
+    gba_kband_params k{};
+    gba_scoring m{};
+    MatrixFromParams(p, m);
+    for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) k.sub[a][b] = m.sub[a][b];
+    k.ins = ins; k.del = del; k.align_type = alignType; k.gap_model = gapModel;
+    k.hp_ins_open = p.indel + 2; k.hp_ins_extend = p.indel - 3; k.ins_open = p.indel + 2; k.ins_extend = p.indel - 1;
+    k.hp_rule = 0; k.tie_break = p.tieBreak; k.max_drops = maxDrops;
+    k.stats_ins = p.indel; k.stats_del = p.indel;
+    return k;
+}
+
+// Any number of (query, target, k) triples through one gba_kband call.
+class KBandBatch {
+public:
+    explicit KBandBatch(gba_ctx *ctx) : ctx_(ctx) {}
+    // profile: 11 costs per query base (see gba.h) or nullptr; all pairs of a batch must agree on having one
+    void Add(const char *q, size_t ql, const char *t, size_t tl, int k, bool reverse = false, const int16_t *profile = nullptr)
+    {
+        q_off_.push_back(q_arena_.size()); q_len_.push_back((uint32_t)ql); q_arena_.append(q, ql);
+        t_off_.push_back(t_arena_.size()); t_len_.push_back((uint32_t)tl); t_arena_.append(t, tl);
+        k_.push_back(k); rev_.push_back(reverse ? 1 : 0);
+        if (profile) prof_.insert(prof_.end(), profile, profile + 11 * ql);
+    }
+    size_t size() const { return k_.size(); }
+    int Run(const gba_kband_params &P)
+    {
+        const uint32_t n = (uint32_t)k_.size();
+        pairs.assign(n, gba_pair_result{});
+        uint64_t cap = n;
+        for (uint32_t i = 0; i < n; i++) cap += std::min(q_len_[i], t_len_[i]);
+        blocks.assign(cap, gba_block{});
+        if (n == 0) return GBA_OK;
+        if (!prof_.empty() && prof_.size() != q_arena_.size() * 11) return GBA_E_INVALID;
+        if (q_arena_.empty()) q_arena_.push_back('N');
+        if (t_arena_.empty()) t_arena_.push_back('N');
+        gba_kband_batch b{};
+        b.n_pairs = n;
+        b.q_arena = (const uint8_t *)q_arena_.data(); b.q_off = q_off_.data(); b.q_len = q_len_.data();
+        b.t_arena = (const uint8_t *)t_arena_.data(); b.t_off = t_off_.data(); b.t_len = t_len_.data();
+        b.q_arena_bytes = q_arena_.size(); b.t_arena_bytes = t_arena_.size();
+        b.k = k_.data(); b.reverse = rev_.data(); b.profile = prof_.empty() ? nullptr : prof_.data();
+        gba_results r{pairs.data(), blocks.data(), cap, 0};
+        return gba_kband(ctx_, &b, &P, &r);
+    }
+    std::vector<gba_pair_result> pairs;
+    std::vector<gba_block> blocks;
+
+private:
+    gba_ctx *ctx_;
+    std::string q_arena_, t_arena_;
+    std::vector<uint64_t> q_off_, t_off_;
+    std::vector<uint32_t> q_len_, t_len_;
+    std::vector<int32_t> k_;
+    std::vector<uint8_t> rev_;
+    std::vector<int16_t> prof_;
+};
+
+inline void StatsInto(AlignmentCandidate &c, const gba_pair_result &p)
+{
+    c.nMatch = p.n_match; c.nMismatch = p.n_mismatch; c.nIns = p.n_ins; c.nDel = p.n_del;
+    const uint32_t cols = c.nMatch + c.nMismatch + c.nIns + c.nDel;
+    c.pctSimilarity = cols ? 100.0f * c.nMatch / cols : 0.0f;
+    c.score = p.score; c.nCells = p.ncells;
+}
+
+// The branch of RefineAlignment without guided alignment (-noUseGuidedAlign, :775-902) for reads without
+// usable quality values: the sequences are cut to the span of the SDP blocks, k = params.bandSize or
+// |drift| * 1.5, at least 10 (:848-861), positions move into the aligned-sequence offsets (:863-887), and
+// PairwiseLocalAlign runs AffineKBandAlign(..., indel+2, indel-3, indel+2, indel-1, indel, k * 1.2, ..., Global)
+// (/root/reference/iblasr/BlasrAlignImpl.hpp:1259-1267), then ComputeAlignmentStats with distScoreFn2 (:1304).
+inline int RefineLegacy(const std::string &read, std::vector<AlignmentCandidate *> &alignmentPtrs,
+                        const MappingParameters &params, gba_ctx *ctx)
+{
+    KBandBatch batch(ctx);
+    std::vector<AlignmentCandidate *> todo;
+    for (AlignmentCandidate *c : alignmentPtrs) {
+        if (c->blocks.empty()) { c->score = 0; continue; }                       // :800-803
+        const Block &first = c->blocks.front(), &last = c->blocks.back();
+        const uint32_t ql = last.qPos + last.length, tl = last.tPos + last.length - first.tPos;
+        const uint32_t qs = c->qPos + c->qAlignedSeqPos;
+        int k = params.bandSize ? params.bandSize : (int)(std::abs(ComputeDrift(c->blocks)) * 1.5);
+        if (k < 10) k = 10;
+        if (qs + (uint64_t)ql > read.size() || c->tPos + (uint64_t)tl > c->tAlignedSeq.size()) { c->status = GBA_PAIR_BAD_GUIDE; continue; }
+        c->tAlignedSeq = c->tAlignedSeq.substr(c->tPos, tl);
+        c->qAlignedSeq = read.substr(qs, ql);
+        c->tAlignedSeqPos += c->tPos; c->tAlignedSeqLength = tl;
+        c->qAlignedSeqPos += c->qPos; c->qAlignedSeqLength = last.qPos + last.length - first.qPos;
+        c->tPos = c->qPos = 0;
+        c->blocks.clear();
+        batch.Add(c->qAlignedSeq.data(), ql, c->tAlignedSeq.data(), tl, (int)(k * 1.2));
+        todo.push_back(c);
+    }
+    const int rc = batch.Run(KBandParams(params, GBA_KB_GLOBAL, GBA_KB_AFFINE_HP, params.indel, params.indel));
+    if (rc != GBA_OK) return rc;
+    for (size_t i = 0; i < todo.size(); i++) {
+        AlignmentCandidate &c = *todo[i];
+        const gba_pair_result &p = batch.pairs[i];
+        c.status = p.status;
+        if (p.status != GBA_PAIR_OK) continue;
+        c.blocks.resize(p.n_blk);
+        for (uint32_t x = 0; x < p.n_blk; x++) { const gba_block &g = batch.blocks[p.blk_off + x]; c.blocks[x] = Block{g.q_pos, g.t_pos, g.length}; }
+        c.nBlocks = p.n_blk;
+        c.qPos = p.q_pos; c.tPos = p.t_pos;
+        StatsInto(c, p);
+        c.qStart = p.q_start; c.qEnd = p.q_end; c.tStart = p.t_start; c.tEnd = p.t_end; c.haveInterval = true;
+    }
+    return GBA_OK;
+}
+
+// The -extend step of AlignIntervals (/root/reference/iblasr/BlasrAlignImpl.hpp:1011-1201) for the candidates
+// of one read on the FORWARD strand of `genome` (a reverse-strand candidate wants the reverse complement
+// of the genome here, whose positions its tAlignedSeqPos counts along): behind the last block up to 500
+// bases of read and genome go through ExtendAlignmentForward (:1086-1099), in front of the first block up
+// to 500 through ExtendAlignmentReverse (:1144-1155), both with AlignIntervals' distScoreFn (:576),
+// extendBandSize and maxExtendDropoff; an extension with a negative score is spliced on (:1102-1120,
+// :1158-1196); counts and score of the pieces add up (:1214 with linear gap costs).  *extended: ends extended.
+inline int ExtendAlignments(const std::string &read, std::vector<AlignmentCandidate *> &alignmentPtrs, const std::string &genome,
+                            const MappingParameters &params, gba_ctx *ctx, int *extended = nullptr,
+                            int extendBandSize = 10, int maxExtendDropoff = 10, uint64_t contigStart = 0, uint64_t contigEnd = UINT64_MAX)
+{
+    const uint64_t maximumExtendLength = 500;                                    // :1039
+    if (contigEnd > genome.size()) contigEnd = genome.size();
+    struct Job { AlignmentCandidate *c; int side; uint64_t q0, t0, rl, gl; };
+    std::vector<Job> jobs;
+    KBandBatch batch(ctx);
+    for (AlignmentCandidate *c : alignmentPtrs) {
+        if (c->blocks.empty()) continue;
+        const Block &last = c->blocks.back();
+        const uint64_t lastQ = (uint64_t)last.qPos + last.length + c->qPos + c->qAlignedSeqPos;
+        const uint64_t lastT = (uint64_t)last.tPos + last.length + c->tPos + c->tAlignedSeqPos;
+        if (lastQ < read.size() && lastT < contigEnd) {
+            const uint64_t rl = std::min<uint64_t>(read.size() - lastQ, maximumExtendLength), gl = std::min<uint64_t>(contigEnd - lastT, maximumExtendLength);
+            jobs.push_back(Job{c, 0, lastQ, lastT, rl, gl});
+            batch.Add(read.data() + lastQ, rl, genome.data() + lastT, gl, extendBandSize, false);
+        }
+        const uint64_t firstQ = (uint64_t)c->qPos + c->qAlignedSeqPos, firstT = (uint64_t)c->tPos + c->tAlignedSeqPos;
+        if (firstQ > 0 && firstT > contigStart) {
+            const uint64_t rl = std::min<uint64_t>(firstQ, maximumExtendLength), gl = std::min<uint64_t>(firstT - contigStart, maximumExtendLength);
+            jobs.push_back(Job{c, 1, firstQ - rl, firstT - gl, rl, gl});
+            batch.Add(read.data() + firstQ - rl, rl, genome.data() + firstT - gl, gl, extendBandSize, true);
+        }
+    }
+    int done = 0;
+    if (extended) *extended = 0;
+    if (jobs.empty()) return GBA_OK;
+    const int rc = batch.Run(KBandParams(params, GBA_KB_EXTEND, GBA_KB_LINEAR, params.insertion, params.deletion, maxExtendDropoff));
+    if (rc != GBA_OK) return rc;
+    for (int order = 0; order < 2; order++) {
+        for (size_t x = 0; x < jobs.size(); x++) {
+            const Job &j = jobs[x];
+            const gba_pair_result &p = batch.pairs[x];
+            if (j.side != order || p.status != GBA_PAIR_OK || p.dp_score >= 0 || p.n_blk == 0) continue;
+            AlignmentCandidate &c = *j.c;
+            const gba_block *eb = &batch.blocks[p.blk_off];
+            const uint64_t oq = (uint64_t)c.qPos + c.qAlignedSeqPos, ot = (uint64_t)c.tPos + c.tAlignedSeqPos;
+            const uint64_t qend = p.q_pos + eb[p.n_blk - 1].q_pos + eb[p.n_blk - 1].length, tend = p.t_pos + eb[p.n_blk - 1].t_pos + eb[p.n_blk - 1].length;
+            const uint32_t qlen = c.qAlignedSeqLength ? c.qAlignedSeqLength : (uint32_t)c.qAlignedSeq.size();
+            if (j.side == 0) {
+                for (uint32_t i = 0; i < p.n_blk; i++)
+                    c.blocks.push_back(Block{(uint32_t)(j.q0 + p.q_pos + eb[i].q_pos - oq), (uint32_t)(j.t0 + p.t_pos + eb[i].t_pos - ot), eb[i].length});
+                c.tAlignedSeq.append(genome, j.t0, tend);
+                c.qAlignedSeqLength = qlen + (uint32_t)qend;
+                c.qAlignedSeq = read.substr(c.qAlignedSeqPos, c.qAlignedSeqLength);
+            } else {
+                std::vector<Block> nb;
+                for (uint32_t i = 0; i < p.n_blk; i++) nb.push_back(Block{eb[i].q_pos, eb[i].t_pos, eb[i].length});
+                const uint64_t nq = j.q0 + p.q_pos, nt = j.t0 + p.t_pos;                 // new origin of the blocks
+                for (const Block &b : c.blocks) nb.push_back(Block{(uint32_t)(b.qPos + oq - nq), (uint32_t)(b.tPos + ot - nt), b.length});
+                c.blocks.swap(nb);
+                c.tAlignedSeq = genome.substr(j.t0, j.gl - c.tPos) + c.tAlignedSeq;
+                c.tAlignedSeqPos = (uint32_t)j.t0; c.qAlignedSeqPos = (uint32_t)j.q0;
+                c.tPos = p.t_pos; c.qPos = p.q_pos;
+                c.qAlignedSeqLength = (uint32_t)j.rl + qlen;
+                c.qAlignedSeq = read.substr(c.qAlignedSeqPos, c.qAlignedSeqLength);
+            }
+            c.tAlignedSeqLength = (uint32_t)c.tAlignedSeq.size();
+            c.nBlocks = (uint32_t)c.blocks.size();
+            c.nMatch += p.n_match; c.nMismatch += p.n_mismatch; c.nIns += p.n_ins; c.nDel += p.n_del;
+            c.score += p.score;
+            const uint32_t cols = c.nMatch + c.nMismatch + c.nIns + c.nDel;
+            c.pctSimilarity = cols ? 100.0f * c.nMatch / cols : 0.0f;
+            c.qStart = c.qPos + c.blocks.front().qPos; c.qEnd = c.qPos + c.blocks.back().qPos + c.blocks.back().length;
+            c.tStart = c.tPos + c.blocks.front().tPos; c.tEnd = c.tPos + c.blocks.back().tPos + c.blocks.back().length;
+            c.haveInterval = true;
+            done++;
+        }
+    }
+    if (extended) *extended = done;
+    return GBA_OK;
+}
+
 // RefineAlignments for ONE read (:905-923): all its candidates in one batch, then the re-sort.
 inline int RefineAlignments(const std::string &read, std::vector<AlignmentCandidate *> &alignmentPtrs,
                             const MappingParameters &params, gba_ctx *ctx, bool wantBlocks = true)
@@ -443,7 +640,7 @@ inline int RefineAlignments(const std::string &read, std::vector<AlignmentCandid
     if (!params.refineAlignments) return GBA_OK;
     int rc;
     if (params.doGlobalAlignment) rc = RefineGlobal(read, alignmentPtrs, params, ctx);
-    else if (!params.useGuidedAlign) return GBA_E_UNSUPPORTED;       // legacy k-band branch (:775-902): not on the accelerated path
+    else if (!params.useGuidedAlign) rc = RefineLegacy(read, alignmentPtrs, params, ctx);      // legacy k-band branch (:775-902)
     else {
         RefineBatch batch(ctx);
         for (AlignmentCandidate *c : alignmentPtrs) batch.Add(read, c);

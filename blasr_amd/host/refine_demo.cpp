@@ -10,6 +10,10 @@
 //   sdp      the guides come from the device first (SDPAlignCandidates: the blocks of the input are ignored), then the batch
 //   fused    SDPAlign and RefineAlignment in one submit (AlignAndRefineCandidates; the blocks of the input are ignored)
 //   intervals  run without a block arena and print per candidate: status score nBlocks qStart qEnd tStart tEnd
+//   legacy   run the branch without guided alignment (RefineLegacy: AffineKBandAlign in a band around the guide's drift)
+//   extend   stdin is n, the genome, then per candidate "read tAlignedSeqPos qAlignedSeqPos nblk blocks..." (its window is the
+//            genome from tAlignedSeqPos over the span of its blocks): the -extend step (ExtendAlignments); prints per candidate
+//            status score qAlignedSeqPos tAlignedSeqPos qPos tPos nblk blocks...
 //   mapqv    no GPU: stdin is n, then "qStart qEnd rawProbScore" per candidate of ONE read; prints their mapQVs
 #include <cstdio>
 #include <iostream>
@@ -39,6 +43,39 @@ int main(int argc, char **argv)
         std::printf("\n");
         return 0;
     }
+    if (mode == "extend") {
+        std::string genome;
+        std::cin >> genome;
+        std::vector<std::string> rd(n);
+        std::vector<gba::AlignmentCandidate> cs(n);
+        for (size_t i = 0; i < n; i++) {
+            size_t nb;
+            std::cin >> rd[i] >> cs[i].tAlignedSeqPos >> cs[i].qAlignedSeqPos >> nb;
+            cs[i].blocks.resize(nb);
+            for (auto &b : cs[i].blocks) std::cin >> b.qPos >> b.tPos >> b.length;
+            const gba::Block &l = cs[i].blocks.back();
+            cs[i].tAlignedSeq = genome.substr(cs[i].tAlignedSeqPos, l.tPos + l.length);
+            cs[i].qAlignedSeqLength = l.qPos + l.length;
+            cs[i].qAlignedSeq = rd[i].substr(cs[i].qAlignedSeqPos, cs[i].qAlignedSeqLength);
+        }
+        gba_ctx *ctx = nullptr;
+        gba_config cfg{0, 0, nullptr};
+        int rc = gba_create(&ctx, &cfg);
+        if (rc != GBA_OK) { std::fprintf(stderr, "gba_create: %s\n", gba_strerror(rc)); return 1; }
+        gba::MappingParameters params;
+        for (size_t i = 0; i < n && rc == GBA_OK; i++) {
+            std::vector<gba::AlignmentCandidate *> one{&cs[i]};
+            rc = gba::ExtendAlignments(rd[i], one, genome, params, ctx);
+        }
+        if (rc != GBA_OK) { std::fprintf(stderr, "ExtendAlignments: %s\n", gba_strerror(rc)); return 1; }
+        for (auto &c : cs) {
+            std::printf("%d %d %u %u %u %u %zu", c.status, c.score, c.qAlignedSeqPos, c.tAlignedSeqPos, c.qPos, c.tPos, c.blocks.size());
+            for (auto &b : c.blocks) std::printf(" %u %u %u", b.qPos, b.tPos, b.length);
+            std::printf("\n");
+        }
+        gba_destroy(ctx);
+        return 0;
+    }
     std::vector<std::string> reads(n);
     std::vector<gba::AlignmentCandidate> cands(n);
     for (size_t i = 0; i < n; i++) {
@@ -52,7 +89,15 @@ int main(int argc, char **argv)
     int rc = gba_create(&ctx, &cfg);
     if (rc != GBA_OK) { std::fprintf(stderr, "gba_create: %s\n", gba_strerror(rc)); return 1; }
     gba::MappingParameters params;
-    if (global) {
+    if (mode == "legacy") {
+        params.useGuidedAlign = false;
+        params.bandSize = 0;
+        params.sortRefinedAlignments = false;
+        for (size_t i = 0; i < n && rc == GBA_OK; i++) {
+            std::vector<gba::AlignmentCandidate *> one{&cands[i]};
+            rc = gba::RefineAlignments(reads[i], one, params, ctx);
+        }
+    } else if (global) {
         params.doGlobalAlignment = true;
         params.sortRefinedAlignments = false;
         for (size_t i = 0; i < n && rc == GBA_OK; i++) {

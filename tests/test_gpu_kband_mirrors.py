@@ -134,3 +134,53 @@ def test_global_branch_with_quality_values(mods, oracle):
     assert (c.score, c.qPos, c.tPos, len(c.blocks)) == (want["score"], want["q_pos"], want["t_pos"], want["n_blk"])
     assert (c.blocks == wb).all()
     ctx.close()
+
+
+def test_cpp_shim_legacy_refine_and_extend(mods, oracle):
+    """refine_demo legacy / extend: gba::RefineLegacy and gba::ExtendAlignments of gba_refine.hpp give what
+    the Python mirrors give on the same candidates."""
+    import os
+    import subprocess
+    from blasr_amd import build
+    api, refine, L = mods
+    exe = build.HOST_DEMO
+    assert os.path.exists(exe), "run python -m blasr_amd.build"
+    rng = np.random.default_rng(77)
+    ctx = api.Context(0)
+    # -- legacy: four reads with sparse exact blocks as guides
+    import difflib
+    params = refine.MappingParameters(useGuidedAlign=False, bandSize=0, sortRefinedAlignments=False)
+    lines, want = ["4"], []
+    for _ in range(4):
+        t = rng.choice(ACGT, 900)
+        read = _read(rng, t[100:800], 0.1, False).tobytes()
+        tw = t.tobytes()
+        mb = [m for m in difflib.SequenceMatcher(None, read, tw, autojunk=False).get_matching_blocks() if m.size >= 12]
+        blk = np.zeros(len(mb), refine.BLOCK_DT)
+        for i, m in enumerate(mb):
+            blk[i] = (m.a - mb[0].a, m.b - mb[0].b, m.size)
+        # the demo's candidates start at (0, 0) of both strings: hand it the strings cut at the first block
+        rd, tg = read[mb[0].a:], tw[mb[0].b:]
+        c = refine.AlignmentCandidate(tAlignedSeq=tg, blocks=blk.copy())
+        refine.refine_legacy(rd, [c], params, ctx)
+        want.append(c)
+        lines.append("%s %s %d %s" % (rd.decode(), tg.decode(), len(blk), " ".join("%d %d %d" % tuple(int(v) for v in b) for b in blk)))
+    out = subprocess.run([exe, "legacy"], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    for row, c in zip(out.stdout.strip().split("\n"), want):
+        v = [int(x) for x in row.split()]
+        assert v[:6] == [c.status, c.score, c.nCells, c.qPos, c.tPos, len(c.blocks)]
+        assert v[6:] == [int(x) for b in c.blocks for x in b]
+    # -- extend: the candidate of test_extend_alignments on the forward strand
+    genome, sseq, read, nl = _case(rng, 0)
+    blk = np.zeros(1, refine.BLOCK_DT); blk[0] = (0, 0, 800)
+    c = refine.AlignmentCandidate(tAlignedSeq=sseq[1600:2400], tAlignedSeqPos=1600, qAlignedSeqPos=nl, blocks=blk,
+                                  qAlignedSeq=read[nl:nl + 800], qAlignedSeqLength=800, tAlignedSeqLength=800)
+    assert refine.ExtendAlignments(read, [c], genome, refine.MappingParameters(), ctx) == 2
+    text = "1\n%s\n%s 1600 %d 1 0 0 800\n" % (genome.decode(), read.decode(), nl)
+    out = subprocess.run([exe, "extend"], input=text, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    v = [int(x) for x in out.stdout.split()]
+    assert v[:7] == [0, c.score, c.qAlignedSeqPos, c.tAlignedSeqPos, c.qPos, c.tPos, len(c.blocks)]
+    assert v[7:] == [int(x) for b in c.blocks for x in b]
+    ctx.close()
