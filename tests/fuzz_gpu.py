@@ -7,7 +7,8 @@ scoring / band / mode parameters, runs both sides and compares every result fiel
 Every second round also asks the device for the CIGAR operations (random flags) and compares a
 sample of pairs with blasr_amd.emit.cigar_ops on the returned blocks; every third round runs the
 guide producer (gba_sdp, random tuple size / penalties / fragment budget) on the round's sequences
-against oracle/sdp_oracle.c.
+against oracle/sdp_oracle.c; every third round runs the fixed-band aligners (gba_kband: random type, gap model, costs,
+bands, strand flags, cost profile) on a sample of the round's sequences against oracle/kband_oracle.c.
 Mismatches are written to gpurun_out/fuzz_fail_<k>.json with everything needed to replay them.
 
 usage: python tests/fuzz_gpu.py [--seconds 120] [--seed 1]
@@ -139,6 +140,62 @@ def check_sdp(rng, api, oracle, _lib, ctx, pool, batch):
     return None, kw
 
 
+def check_kband(rng, api, oracle, _lib, ctx, pool, batch):
+    """gba_kband with random type / gap model / costs / bands / strand flags / cost profile on (a sample of) the round's
+    sequences against oracle/kband_oracle.c."""
+    n_all = int(batch["n_pairs"])
+    pick = rng.choice(n_all, min(n_all, 48), replace=False)
+    at = int(rng.integers(0, 3)); gm = int(rng.integers(0, 2))
+    use_prof = gm == 0 and rng.random() < 0.4
+    kw = dict(align_type=at, gap_model=gm, match=int(rng.integers(-30, 3)), mismatch=int(rng.integers(0, 40)), n_score=int(rng.integers(-5, 8)),
+              ins=int(rng.integers(0, 40)), dele=int(rng.integers(0, 40)), indel=int(rng.integers(0, 12)), hp_rule=int(rng.integers(0, 2)),
+              tie_break=int(rng.integers(0, 2)), max_drops=int(rng.choice([0, 1, 3, 10, 40])),
+              hp_ins_open=int(rng.integers(0, 20)), hp_ins_extend=int(rng.integers(0, 12)), ins_open=int(rng.integers(0, 20)), ins_extend=int(rng.integers(0, 12)))
+    if rng.random() < 0.3:
+        kw.update(stats_affine=1, stats_affine_open=int(rng.integers(0, 12)), stats_affine_extend=int(rng.integers(0, 6)))
+    P = api.make_kband_params(**kw)
+    pairs, ks, rev = [], [], []
+    for p in pick:
+        qo, ql = int(batch["q_off"][p]), int(batch["q_len"][p])
+        to, tl = int(batch["t_off"][p]), int(batch["t_len"][p])
+        if at == _lib.KB_EXTEND:
+            ql, tl = min(ql, 1500), min(tl, 1500)
+        pairs.append((np.ascontiguousarray(batch["q_arena"][qo:qo + ql]), np.ascontiguousarray(batch["t_arena"][to:to + tl])))
+        base = abs(ql - tl) if rng.random() < 0.8 else 0
+        ks.append(int(min(255, base + int(rng.choice([0, 1, 5, 10, 30, 80])))))
+        rev.append(int(rng.random() < 0.4))
+    from kband_cases import pack, random_profile
+    prof = random_profile(rng, pairs) if use_prof else None
+    b = pack(pairs, ks, profile=prof, reverse=np.array(rev, np.uint8))
+    got, blocks, rc = ctx.kband_host(b, P)
+    if rc != 0:
+        return (0, "kband_rc", 0, rc), kw
+
+    def one(i):
+        q, t = pairs[i]
+        pr = None
+        if prof is not None:
+            o = int(b["q_off"][i])
+            pr = prof[o * 11:(o + len(q)) * 11]
+        return oracle.kband_align(q, t, ks[i], P, profile=pr, reverse=bool(rev[i]))
+    want = list(pool.map(one, range(len(pairs))))
+    for i, (w, wb) in enumerate(want):
+        g = got[i]
+        if int(g["status"]) == _lib.PAIR_TOO_LONG:
+            continue
+        if int(g["status"]) != w["status"]:
+            return (int(pick[i]), "kband_status", w["status"], int(g["status"]), ks[i], rev[i]), kw
+        if w["status"] != 0:
+            continue
+        for fld in FIELDS:
+            if int(g[fld]) != int(w[fld]):
+                return (int(pick[i]), "kband_" + fld, int(w[fld]), int(g[fld]), ks[i], rev[i]), kw
+        kb = blocks[int(g["blk_off"]):int(g["blk_off"]) + int(g["n_blk"])]
+        if len(kb) != len(wb) or not (kb == wb).all():
+            return (int(pick[i]), "kband_blocks", len(wb), len(kb), ks[i], rev[i]), kw
+    return None, kw
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
@@ -151,7 +208,7 @@ def main():
     ctx = api.Context(0)
     pool = ThreadPoolExecutor(16)
     t_end = time.time() + args.seconds
-    rounds = pairs_done = fails = unsupported = cigar_rounds = sdp_rounds = 0
+    rounds = pairs_done = fails = unsupported = cigar_rounds = sdp_rounds = kband_rounds = 0
     hist = {}
     modes = {}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -222,6 +279,11 @@ def main():
             sdp_rounds += 1
             if bad:
                 kw = dict(kw, sdp=skw)
+        if not bad and rounds % 3 == 1:
+            bad, kkw = check_kband(rng, api, oracle, _lib, ctx, pool, batch)
+            kband_rounds += 1
+            if bad:
+                kw = dict(kw, kband=kkw)
         rounds += 1; pairs_done += n
         for v, c in zip(*np.unique(pairs["status"], return_counts=True)):
             hist[int(v)] = hist.get(int(v), 0) + int(c)
@@ -244,7 +306,7 @@ def main():
         if rounds % 20 == 0:
             print("rounds %d pairs %d fails %d unsupported-scoring %d" % (rounds, pairs_done, fails, unsupported), flush=True)
     print("DONE rounds %d pairs %d fails %d unsupported-scoring %d" % (rounds, pairs_done, fails, unsupported), flush=True)
-    print("status histogram", hist, "pairs per mode", modes, "rounds with CIGAR check", cigar_rounds, "rounds with guide production", sdp_rounds, flush=True)
+    print("status histogram", hist, "pairs per mode", modes, "rounds with CIGAR check", cigar_rounds, "rounds with guide production", sdp_rounds, "rounds with fixed-band aligners", kband_rounds, flush=True)
     sys.exit(1 if fails else 0)
 
 
