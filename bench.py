@@ -145,6 +145,50 @@ def host_child(args):
     pipe.close()
 
 
+def fixed_band(api, _lib, host, n, threads):
+    """The aligner of the -extend step on the batch's own sequences: the last 500 bases of every read against the last
+    500 of its window, backwards from their ends (ExtendAlignmentReverse's shape: band 10, drop-off 10), through
+    gba_kband from host memory to host memory; then the CPU restatement of the same on `threads` cores."""
+    m = min(n, 65536)
+    ql = np.minimum(host["q_len"][:m], 500).astype(np.uint32); tl = np.minimum(host["t_len"][:m], 500).astype(np.uint32)
+    qs = (host["q_off"][:m] + host["q_len"][:m] - ql).astype(np.int64); ts = (host["t_off"][:m] + host["t_len"][:m] - tl).astype(np.int64)
+    q_off = np.zeros(m, np.uint64); t_off = np.zeros(m, np.uint64)
+    q_off[1:] = np.cumsum(ql[:-1].astype(np.uint64)); t_off[1:] = np.cumsum(tl[:-1].astype(np.uint64))
+    b = {"n_pairs": m, "q_arena": np.concatenate([host["q_arena"][qs[i]:qs[i] + ql[i]] for i in range(m)]),
+         "t_arena": np.concatenate([host["t_arena"][ts[i]:ts[i] + tl[i]] for i in range(m)]),
+         "q_off": q_off, "q_len": ql, "t_off": t_off, "t_len": tl, "k": np.full(m, 10, np.int32), "reverse": np.ones(m, np.uint8)}
+    P = api.make_kband_params(align_type=_lib.KB_EXTEND, ins=4, dele=5, max_drops=10)
+    ctx = api.Context(0)
+    ctx.kband_host(b, P)
+    t0 = time.perf_counter()
+    pairs, blocks, rc = ctx.kband_host(b, P)
+    dt = time.perf_counter() - t0
+    ctx.close()
+    ok = pairs["status"] == 0
+    r = {"what": "gba_kband, GBA_KB_EXTEND backwards from the ends of the batch's reads and windows (500 x 500, band 10, drop-off 10), host to host",
+         "pairs": m, "ms": round(dt * 1e3, 3), "extensions_per_sec": round(m / dt, 1), "gcups": round(int(pairs["ncells"][ok].sum()) / dt / 1e9, 2),
+         "pairs_ok": int(ok.sum()), "extended": int((pairs["dp_score"][ok] < 0).sum()), "rc": rc}
+    if threads:
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import oracle as _o
+
+        def one(i):
+            q = b["q_arena"][int(q_off[i]):int(q_off[i]) + int(ql[i])]
+            t = b["t_arena"][int(t_off[i]):int(t_off[i]) + int(tl[i])]
+            return _o.kband_align(q, t, 10, P, reverse=True)[0]
+        done, t1, cells, same = 0, time.perf_counter(), 0, True
+        with ThreadPoolExecutor(threads) as pool:
+            while time.perf_counter() - t1 < 3.0 and done + 64 * threads <= m:
+                for i, w in zip(range(done, done + 64 * threads), pool.map(one, range(done, done + 64 * threads))):
+                    cells += w["ncells"]
+                    same = same and (w["dp_score"], w["score"], w["n_blk"]) == (int(pairs[i]["dp_score"]), int(pairs[i]["score"]), int(pairs[i]["n_blk"]))
+                done += 64 * threads
+        secs = time.perf_counter() - t1
+        r["cpu_baseline"] = {"extensions_per_sec": round(done / secs, 1), "gcups": round(cells / secs / 1e9, 3), "cores": threads, "kind": "port",
+                             "same_results": same, "sample": "%d pairs in %.1f s (oracle/kband_oracle.c through ctypes, %d threads)" % (done, secs, threads)}
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,6 +202,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host", action="store_true", help="skip the host-to-host measurement")
     ap.add_argument("--no-guides", action="store_true", help="skip the guide-production measurement")
+    ap.add_argument("--no-fixed-band", action="store_true", help="skip the gba_kband (end extension) measurement")
     ap.add_argument("--cigar", type=int, default=None, help="also have the device write CIGAR operations (GBA_CIGAR_* flags); not part of the default line")
     ap.add_argument("--host-steps", type=int, default=6)
     ap.add_argument("--host-contexts", type=int, default=2)
@@ -395,6 +440,8 @@ def main():
             secs = time.perf_counter() - t1
             out["guide_production"]["cpu_baseline"] = {"pairs_per_sec": round(done / secs, 1), "cores": threads, "kind": "port",
                                                        "sample": "%d pairs in %.1f s (oracle/sdp_oracle.c, one pair per call, %d threads)" % (done, secs, threads)}
+    if rank == 0 and world == 1 and not args.no_fixed_band:
+        out["fixed_band"] = fixed_band(api, _lib, host, n, None if args.no_cpu else host_cores())
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
