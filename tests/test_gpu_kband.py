@@ -155,3 +155,23 @@ def test_block_arena_too_small_and_no_arena(api, oracle):
     assert ((part["status"] == _lib.PAIR_NOSPACE) == ~fits).all()
     assert (pblocks[: int(full["n_blk"][fits].sum())] == blocks[: int(full["n_blk"][fits].sum())]).all()
     ctx.close()
+
+
+def test_golden_fixture_through_the_library(api, oracle):
+    """tests/golden/kband_small.json (the oracle's outputs, committed) against the kernels."""
+    import json
+    import os
+    from blasr_amd import _lib
+    with open(os.path.join(os.path.dirname(__file__), "golden", "kband_small.json")) as f:
+        cases = json.load(f)["cases"]
+    ctx = api.Context(0)
+    for c in cases:
+        q, t = np.frombuffer(c["q"].encode(), np.uint8), np.frombuffer(c["t"].encode(), np.uint8)
+        prof = np.array(c["profile"], np.int16) if c["profile"] is not None else None
+        got, blocks, rc = ctx.kband_host(pack([(q, t)], [c["k"]], profile=prof, reverse=np.array([c["reverse"]], np.uint8)),
+                                         api.make_kband_params(**c["params"]))
+        assert rc == 0
+        for f_ in FIELDS:
+            assert int(got[0][f_]) == c["result"][f_], (c["set"], f_)
+        assert [[int(x["q_pos"]), int(x["t_pos"]), int(x["length"])] for x in blocks] == c["blocks"], c["set"]
+    ctx.close()

@@ -107,3 +107,22 @@ def test_homopolymer_insertions_are_cheaper(oracle, P):
     pl, _ = oracle.kband_align(_u8("CCTTTCGG"), _u8("CCCGG"), 4, prm)
     assert hp["dp_score"] == -25 + 7 + 2 + 2 and hp["n_ins"] == 3
     assert pl["dp_score"] == -25 + 7 + 4 + 4 and pl["n_ins"] == 3
+
+
+def _golden():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "kband_small.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_oracle_matches_golden(oracle, P):
+    api, L = P
+    cases = _golden()
+    assert len(cases) >= 40
+    for c in cases:
+        prm = api.make_kband_params(**c["params"])
+        pr = np.array(c["profile"], np.int16) if c["profile"] is not None else None
+        r, b = oracle.kband_align(c["q"].encode(), c["t"].encode(), c["k"], prm, profile=pr, reverse=c["reverse"])
+        assert {a: int(v) for a, v in r.items()} == c["result"], c["set"]
+        assert [[int(x["q_pos"]), int(x["t_pos"]), int(x["length"])] for x in b] == c["blocks"], c["set"]
