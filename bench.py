@@ -119,6 +119,26 @@ def host_child(args):
     dt_iv = (time.perf_counter() - t1) / args.host_steps
     iv_same = rc2 == 0 and needed2 == needed and results_digest(pairs, blocks[:0])[:3] == dig_full[:3]
     h2d = sum(hb[x].nbytes for x in ("q_arena", "blocks", "q_off", "t_off", "blk_off", "q_len", "t_len", "n_blk", "t_rc"))
+    # the same batches with their reads 2 bits per base (gba_batch.q_packed): a quarter of the read bytes cross the link
+    pk = api.pack_reads_2bit(host)
+    pbufs = []
+    for b in bufs:
+        qa = pipe.host_array(len(pk["q_arena"]), np.uint8)
+        qa[...] = pk["q_arena"]
+        pbufs.append(dict(b[0], q_arena=qa, q_bases=pk["q_bases"], q_packed=1))
+    del pk
+    for b in bufs:
+        b[1]["score"][:] = 0
+    t1 = time.perf_counter()
+    pipe.submit(pbufs[0], bufs[0][1], bufs[0][2])
+    for i in range(args.host_steps):
+        if i + 1 < args.host_steps:
+            j = (i + 1) % args.host_contexts
+            pipe.submit(pbufs[j], bufs[j][1], bufs[j][2])
+        rc4, needed4 = pipe.wait()
+    dt_pk = (time.perf_counter() - t1) / args.host_steps
+    pk_same = rc4 == 0 and results_digest(pairs, blocks[:needed4]) == dig_full
+    h2d_pk = h2d - hb["q_arena"].nbytes + pbufs[0]["q_arena"].nbytes
     cells_guided = int(pairs["ncells"][pairs["status"] == 0].sum())
     # from sequences alone: the batches without their guide blocks, the guides made on the device in the same call
     pipe.set_guide_producer(api.make_sdp_params(max_fragments=1024 if cfg["read_len"] <= 25_000 else 4096))
@@ -141,7 +161,8 @@ def host_child(args):
     h2d_seq = sum(seqs[0][x].nbytes for x in seqs[0] if x != "n_pairs")
     print(json.dumps({"ms_per_step": dt * 1e3, "h2d_bytes": h2d, "d2h_bytes": n * _lib.PAIR_RESULT_DT.itemsize + needed * _lib.BLOCK_DT.itemsize,
                       "cells": cells_guided, "digest": dig_full, "from_sequences": from_seq, "h2d_bytes_sequences": h2d_seq,
-                      "intervals_ms_per_step": dt_iv * 1e3, "intervals_ok": bool(iv_same)}), flush=True)
+                      "intervals_ms_per_step": dt_iv * 1e3, "intervals_ok": bool(iv_same),
+                      "packed_ms_per_step": dt_pk * 1e3, "packed_h2d_bytes": h2d_pk, "packed_ok": bool(pk_same)}), flush=True)
     pipe.close()
 
 
@@ -408,6 +429,9 @@ def main():
                                                       "d2h_gb": round(n * 88 / 1e9, 3), "ok": h["intervals_ok"],
                                                       "what": "the same batches with gba_results.blocks == NULL: pair results (score, counts, "
                                                               "aligned interval) only, as interval (-m 4) output needs"},
+                                   "packed_reads": {"gcups": round(h["cells"] / (h["packed_ms_per_step"] / 1e3) / 1e9, 2), "ms_per_step": round(h["packed_ms_per_step"], 3),
+                                                    "h2d_gb": round(h["packed_h2d_bytes"] / 1e9, 3), "same_results": h["packed_ok"],
+                                                    "what": "the same batches with the reads 2 bits per base (gba_batch.q_packed), spelt out on the device part by part"},
                                    "from_sequences": {
                                        "what": "the same batches WITHOUT their guide blocks (gba_set_guide_producer): reads and windows in, guides made "
                                                "on the device, refined alignments out; nothing of a guide crosses the link",

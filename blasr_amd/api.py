@@ -64,15 +64,48 @@ def make_batch_struct(batch):
         ("q_off", np.uint64), ("t_off", np.uint64), ("blk_off", np.uint64),
         ("q_len", np.uint32), ("t_len", np.uint32), ("n_blk", np.uint32), ("t_rc", np.uint8))
         if batch.get(k) is not None}
+    packed = bool(batch.get("q_packed"))
+    if packed and len(keep["q_arena"]) < (int(batch["q_bases"]) + 15) // 16 * 4:
+        raise ValueError("packed q_arena shorter than ((q_bases + 15) / 16) * 4 bytes")
     ta = keep.get("t_arena")          # absent: windows of the reference given to set_reference
     bl = keep.get("blocks")           # absent: the guides are made on the device (Context.set_guide_producer)
     b = Batch(n, _ptr(keep["q_arena"]), _ptr(keep["q_off"]), _ptr(keep["q_len"]),
               _ptr(ta) if ta is not None else None, _ptr(keep["t_off"]), _ptr(keep["t_len"]),
               _ptr(bl) if bl is not None else None, _ptr(keep["blk_off"]) if bl is not None else None,
               _ptr(keep["n_blk"]) if bl is not None else None,
-              keep["q_arena"].size, ta.size if ta is not None else 0, bl.size if bl is not None else 0,
-              _ptr(keep["t_rc"]) if "t_rc" in keep else None)
+              int(batch["q_bases"]) if packed else keep["q_arena"].size, ta.size if ta is not None else 0, bl.size if bl is not None else 0,
+              _ptr(keep["t_rc"]) if "t_rc" in keep else None, 1 if packed else 0)
     return b, keep
+
+
+def pack_reads_2bit(batch):
+    """The batch with its reads 2 bits per base (gba_batch.q_packed): q_arena becomes the packed bytes, q_bases the
+    number of bases it stands for; offsets and lengths are unchanged.  Raises for a letter outside ACGT / acgt."""
+    q = np.ascontiguousarray(batch["q_arena"], dtype=np.uint8)
+    code = np.full(256, 255, np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+        code[ch + 32] = i
+    c = code[q]
+    n = len(c)
+    bad = np.flatnonzero(c == 255)
+    if len(bad):
+        # only bytes that belong to a read count (an arena may have unused bytes between its reads): a byte is inside a
+        # read when, among the reads that start at or before it, one ends behind it
+        off = np.asarray(batch["q_off"], np.int64); end = off + np.asarray(batch["q_len"], np.int64)
+        order = np.argsort(off, kind="stable")
+        start, reach = off[order], np.maximum.accumulate(end[order])
+        idx = np.searchsorted(start, bad, side="right") - 1
+        if ((idx >= 0) & (bad < reach[np.maximum(idx, 0)])).any():
+            raise ValueError("reads with letters outside ACGT cannot travel packed")
+        c[bad] = 0
+    if n % 16:
+        c = np.concatenate([c, np.zeros(16 - n % 16, np.uint8)])
+    c = c.reshape(-1, 4)
+    packed = c[:, 0] | (c[:, 1] << 2) | (c[:, 2] << 4) | (c[:, 3] << 6)
+    out = dict(batch)
+    out["q_arena"], out["q_bases"], out["q_packed"] = packed, n, 1
+    return out
 
 
 class Context:
@@ -147,6 +180,9 @@ class Context:
                 a = self.host_array(np.shape(batch[k]), dt)
                 a[...] = batch[k]
                 out[k] = a
+        for k in ("q_packed", "q_bases"):
+            if k in batch:
+                out[k] = batch[k]
         return out
 
     def submit_host(self, batch, pairs, blocks, cigar=None):

@@ -1450,6 +1450,25 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
 }
 
 // ---------------------------------------------------------------- results
+// Reads that travelled 2 bits per base (gba_batch.q_packed) are spelt out as letters where the kernels expect them:
+// one thread per 16 bases (one packed dword in, 16 letters out).
+__global__ __launch_bounds__(256) void k_unpack2(const uint32_t *pk, u32x4 *out, uint64_t first16, uint64_t n16)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    const uint32_t w = pk[first16 + i];
+    u32x4 o;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const uint32_t byte = (w >> (8 * b)) & 255u;
+        uint32_t v = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) v |= ((0x54474341u >> (8 * ((byte >> (2 * x)) & 3u))) & 255u) << (8 * x);     // "ACGT"[code]
+        o[b] = v;
+    }
+    out[first16 + i] = o;
+}
+
 __global__ void k_results_init(Dev d, gba_pair_result *res)
 {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2162,6 +2181,7 @@ struct gba_ctx {
     Slot slot[NSLOT];
     // host-buffer batches: device copies of the caller's batch, the copy streams, the worker thread
     Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res, s_cigoff, s_gout;
+    Buf s_qpk;                       // host-buffer batches with packed reads: the packed bytes as they arrive
     Buf kb[9];                       // gba_kband: band widths, strand flags, cost profile, arrow offsets, matrix, arrows, block slots, counts, offsets
     hipStream_t s_in = nullptr, s_out = nullptr;     // host-to-device and device-to-host copies, beside the kernels
     std::vector<hipEvent_t> ev_in;                   // per part: its inputs have arrived
@@ -2453,6 +2473,11 @@ int stage_part(gba_ctx *c, HostIO &io, uint32_t first, uint32_t cnt, hipEvent_t 
             lo = o < lo ? o : lo; hi = o + l > hi ? o + l : hi;
         }
         if (lo >= hi) continue;
+        const bool packed = a.which == 0 && b.q_packed;
+        if (packed) {       // packed reads move and are spelt out 16 bases at a time
+            const uint64_t top = (a.extent + 15) & ~15ull;
+            lo &= ~15ull; hi = (hi + 15) & ~15ull; hi = hi < top ? hi : top;
+        }
         uint64_t *have = io.have[a.which];
         uint64_t pieces[2][2]; int np = 0;
         if (have[0] >= have[1]) { pieces[np][0] = lo; pieces[np][1] = hi; np++; have[0] = lo; have[1] = hi; }
@@ -2461,6 +2486,15 @@ int stage_part(gba_ctx *c, HostIO &io, uint32_t first, uint32_t cnt, hipEvent_t 
             if (hi > have[1]) { pieces[np][0] = have[1]; pieces[np][1] = hi; np++; have[1] = hi; }
         }
         for (int k = 0; k < np; k++) {
+            if (packed) {
+                const uint64_t f16 = pieces[k][0] / 16, n16 = (pieces[k][1] - pieces[k][0]) / 16;
+                int rc = move((char *)c->s_qpk.ptr + f16 * 4, a.src + f16 * 4, (size_t)n16 * 4);
+                if (rc) return rc;
+                hipLaunchKernelGGL(k_unpack2, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const uint32_t *)c->s_qpk.ptr,
+                                   (u32x4 *)a.buf->ptr, f16, n16);
+                HIPCHK(c, hipGetLastError());
+                continue;
+            }
             int rc = move((char *)a.buf->ptr + pieces[k][0] * a.esz, a.src + pieces[k][0] * a.esz,
                           (size_t)(pieces[k][1] - pieces[k][0]) * a.esz);
             if (rc) return rc;
@@ -2911,6 +2945,7 @@ void gba_destroy(gba_ctx *c)
                  &c->s_nblk, &c->s_res, &c->s_cigoff, &c->s_gout};
     for (Buf *b : bs) release(*b);
     for (auto &b : c->kb) release(b);
+    release(c->s_qpk);
     if (c->h_needed) (void)hipHostFree(c->h_needed);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (int h = 0; h < NSLOT; h++) {
@@ -3009,7 +3044,7 @@ int gba_set_scoring(gba_ctx *c, const gba_scoring *s)
 
 int gba_submit_device(gba_ctx *c, const gba_batch *b, gba_results *out)
 {
-    if (!c || !b || !out) return GBA_E_INVALID;
+    if (!c || !b || !out || b->q_packed) return GBA_E_INVALID;
     if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
     if (b->n_pairs && (!out->pairs || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
     if (out->cigar_ops && !out->cigar_off) return GBA_E_INVALID;
@@ -3027,7 +3062,7 @@ int gba_submit_device(gba_ctx *c, const gba_batch *b, gba_results *out)
 
 int gba_submit_device_noalloc(gba_ctx *c, const gba_batch *b, gba_results *out)
 {
-    if (!c || !b || !out) return GBA_E_INVALID;
+    if (!c || !b || !out || b->q_packed) return GBA_E_INVALID;
     if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
     if (b->n_pairs && (!out->pairs || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
     if (out->cigar_ops && !out->cigar_off) return GBA_E_INVALID;
@@ -3068,7 +3103,7 @@ static int run_host_batch(gba_ctx *c, const gba_batch *b, gba_results *out)
         {&c->s_qoff, (size_t)n * 8}, {&c->s_toff, (size_t)n * 8}, {&c->s_boff, (size_t)n * 8},
         {&c->s_qlen, (size_t)n * 4}, {&c->s_tlen, (size_t)n * 4}, {&c->s_nblk, (size_t)n * 4},
         {&c->s_trc, b->t_rc ? (size_t)n : 0}, {&c->s_res, (size_t)n * sizeof(gba_pair_result)},
-        {&c->s_cigoff, cig ? ((size_t)n + 1) * 8 : 0}};
+        {&c->s_cigoff, cig ? ((size_t)n + 1) * 8 : 0}, {&c->s_qpk, b->q_packed ? (size_t)b->q_arena_bytes / 4 + 16 : 0}};
     for (auto &x : need) if ((rc = ensure(c, *x.buf, x.bytes + 16))) return rc;
     gba_batch db = *b;
     db.q_arena = (const uint8_t *)c->s_q.ptr; db.t_arena = b->t_arena ? (const uint8_t *)c->s_t.ptr : nullptr;
@@ -3216,7 +3251,7 @@ int gba_set_guide_producer(gba_ctx *c, const gba_sdp_params *sp)
 
 int gba_sdp_device(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides *out)
 {
-    if (!c || !b || !sp || !out) return GBA_E_INVALID;
+    if (!c || !b || !sp || !out || b->q_packed) return GBA_E_INVALID;
     if (c->in_flight) return GBA_E_STATE;
     if (b->n_pairs && (!b->q_arena || !b->q_off || !b->t_off || !b->q_len || !b->t_len)) return GBA_E_INVALID;
     if (b->n_pairs && (!out->status || !out->chain_score || !out->n_blk || !out->blk_off || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
@@ -3227,7 +3262,7 @@ int gba_sdp_device(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba
 // The same from and to host buffers: the sequences travel in, the guides travel out (synchronous).
 int gba_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides *out)
 {
-    if (!c || !b || !sp || !out) return GBA_E_INVALID;
+    if (!c || !b || !sp || !out || b->q_packed) return GBA_E_INVALID;
     if (c->in_flight) return GBA_E_STATE;
     const uint32_t n = b->n_pairs;
     out->blocks_needed = 0;

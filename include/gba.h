@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GBA_VERSION 350   /* major*10000 + minor*100 + patch */
+#define GBA_VERSION 360   /* major*10000 + minor*100 + patch */
 
 /* return codes of the entry points */
 enum {
@@ -132,6 +132,11 @@ typedef struct {
     const gba_block *blocks; const uint64_t *blk_off; const uint32_t *n_blk;
     uint64_t q_arena_bytes, t_arena_bytes, n_blocks_total;   /* extents of the three arenas */
     const uint8_t *t_rc;        /* per pair, nonzero: target = reverse complement of its slice; NULL: none */
+    uint32_t q_packed;          /* gba_submit only.  Nonzero: q_arena holds the reads 2 bits per base instead of letters: base x of
+                                   the arena is bits 2 (x & 3) .. 2 (x & 3) + 1 of byte x >> 2, A, C, G, T = 0 .. 3 (a read with
+                                   other letters cannot be packed: send that batch as letters).  q_off, q_len and q_arena_bytes
+                                   still count BASES; the packed arena holds ((q_arena_bytes + 15) / 16) * 4 bytes.  A quarter
+                                   of the bytes cross the link; the device spells the letters out again as each part arrives. */
 } gba_batch;
 
 /* what RefineAlignment copies back into the candidate (BlasrUtilsImpl.hpp:745-772) */

@@ -193,3 +193,33 @@ def test_host_mirrors_one_call_equals_two_calls(api, synth):
     rows = [o.stdout.strip().split("\n") for o in out]
     assert len(rows[0]) == 8 and rows[0][:5] + rows[0][6:] == rows[1][:5] + rows[1][6:]
     assert rows[0][5].split()[0] != "0" and rows[1][5].split()[0] == "1"      # the pair without anchors
+
+
+def test_reads_packed_two_bits_per_base(monkeypatch):
+    """gba_batch.q_packed: the same batch with its reads as letters and 2 bits per base gives the same bytes back,
+    with guides from the caller and with guides made on the device, in one part and in several."""
+    from blasr_amd import api, synth
+    host = synth.compact_blocks(synth.generate(600, read_len=1500, len_jitter=600, seed=91))
+    packed = api.pack_reads_2bit(host)
+    assert len(packed["q_arena"]) * 4 >= len(host["q_arena"]) and packed["q_bases"] == len(host["q_arena"])
+    for part_pairs in ("0", "97"):
+        monkeypatch.setenv("GBA_PART_PAIRS", part_pairs)
+        ctx = api.Context(0)
+        ctx.set_scoring(api.make_scoring())
+        want, wblocks, rc = ctx.refine_host(host)
+        assert rc == 0 and int((want["status"] == 0).sum()) == 600
+        for b in (packed, ctx.pinned_copy(packed)):
+            got, gblocks, rc = ctx.refine_host(b)
+            assert rc == 0 and got.tobytes() == want.tobytes() and gblocks.tobytes() == wblocks.tobytes()
+        # guides made on the device from the packed reads
+        ctx.set_guide_producer(api.make_sdp_params())
+        noguide = {k: v for k, v in host.items() if k not in ("blocks", "blk_off", "n_blk")}
+        want2, wb2, rc = ctx.refine_host(noguide)
+        got2, gb2, rc2 = ctx.refine_host({k: v for k, v in packed.items() if k not in ("blocks", "blk_off", "n_blk")})
+        assert rc == 0 and rc2 == 0 and got2.tobytes() == want2.tobytes() and gb2.tobytes() == wb2.tobytes()
+        ctx.close()
+    # letters that have no 2-bit code are refused by the packer
+    bad = dict(host, q_arena=host["q_arena"].copy())
+    bad["q_arena"][int(host["q_off"][3]) + 5] = ord("N")
+    with pytest.raises(ValueError):
+        api.pack_reads_2bit(bad)
