@@ -64,7 +64,7 @@ class Batch(C.Structure):
         ("t_arena", C.c_void_p), ("t_off", C.c_void_p), ("t_len", C.c_void_p),
         ("blocks", C.c_void_p), ("blk_off", C.c_void_p), ("n_blk", C.c_void_p),
         ("q_arena_bytes", C.c_uint64), ("t_arena_bytes", C.c_uint64), ("n_blocks_total", C.c_uint64),
-        ("t_rc", C.c_void_p), ("q_packed", C.c_uint32),
+        ("t_rc", C.c_void_p), ("q_packed", C.c_uint32), ("q_profile", C.c_void_p),
     ]
 
 

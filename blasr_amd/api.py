@@ -75,6 +75,11 @@ def make_batch_struct(batch):
               _ptr(keep["n_blk"]) if bl is not None else None,
               int(batch["q_bases"]) if packed else keep["q_arena"].size, ta.size if ta is not None else 0, bl.size if bl is not None else 0,
               _ptr(keep["t_rc"]) if "t_rc" in keep else None, 1 if packed else 0)
+    if batch.get("q_profile") is not None:
+        keep["q_profile"] = np.ascontiguousarray(batch["q_profile"], dtype=np.int16)
+        if keep["q_profile"].size != 11 * int(b.q_arena_bytes):
+            raise ValueError("q_profile must hold 11 costs per base of q_arena")
+        b.q_profile = _ptr(keep["q_profile"])
     return b, keep
 
 
@@ -183,6 +188,10 @@ class Context:
         for k in ("q_packed", "q_bases"):
             if k in batch:
                 out[k] = batch[k]
+        if batch.get("q_profile") is not None:
+            a = self.host_array(np.shape(batch["q_profile"]), np.int16)
+            a[...] = batch["q_profile"]
+            out["q_profile"] = a
         return out
 
     def submit_host(self, batch, pairs, blocks, cigar=None):
@@ -345,6 +354,9 @@ class Context:
                   dbatch["n_blk"].data_ptr() if gb is not None else None,
                   dbatch["q_arena"].numel(), ta.numel() if ta is not None else 0, gb.shape[0] if gb is not None else 0,
                   trc.data_ptr() if trc is not None else None)
+        if dbatch.get("q_profile") is not None:       # int16 tensor, 11 per base of q_arena
+            assert dbatch["q_profile"].element_size() == 2 and dbatch["q_profile"].numel() == 11 * dbatch["q_arena"].numel()
+            b.q_profile = dbatch["q_profile"].data_ptr()
         assert out_pairs.numel() * out_pairs.element_size() >= n * PAIR_RESULT_DT.itemsize
         r = Results(out_pairs.data_ptr(), out_blocks.data_ptr() if out_blocks is not None else None,
                     out_blocks.shape[0] if out_blocks is not None else 0, 0)
@@ -474,4 +486,6 @@ def to_device(batch, device="cuda:0"):
     if guides:
         blk = np.ascontiguousarray(batch["blocks"], dtype=BLOCK_DT)
         d["blocks"] = torch.from_numpy(blk.view(np.uint32).reshape(-1, 3).view(np.int32)).to(device)
+    if batch.get("q_profile") is not None:
+        d["q_profile"] = torch.from_numpy(np.ascontiguousarray(batch["q_profile"], dtype=np.int16)).to(device)
     return d

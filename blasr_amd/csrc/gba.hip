@@ -93,6 +93,7 @@ struct Dev {                  // per-batch device state, SoA per pair
     const uint32_t *q_len, *t_len, *n_blk;
     const gba_block *blocks;
     const int32_t *guide_status;   // guides made by the library itself: why a pair has none (null: the caller's guides)
+    const int16_t *prof;           // costs of a quality-value scorer, 11 per byte of q_arena (null: matrix, ins, del)
     // per pair
     int32_t *status;
     uint32_t *qS, *tS, *Q, *T, *rows, *cols, *wcap, *span, *lo_last, *cls, *order, *recdw;
@@ -109,7 +110,7 @@ struct Dev {                  // per-batch device state, SoA per pair
 struct FillConst {
     uint32_t mrow[10];        // per query code: 8 bytes = 0, then biased substitution costs against target codes A,C,G,T,N,N,N
     int32_t cU, cL;           // (cost << S) + (arrow code << 3) [+ row bias for the vertical move]; S = 5 linear, 6 affine
-    int32_t del;
+    int32_t del, ins;
     // affine only: gap-state constants and the row-0 diagonal that makes cell (0,0) cost 0
     int32_t cIO, cIE, cDO, cDE, diag0;
 };
@@ -921,9 +922,17 @@ __device__ __forceinline__ int32_t wave_scan_min(int32_t v, int32_t identity)
     return v;
 }
 
-template <int NB>
+//
+// QV: the costs come from a quality-value scorer's profile (Dev.prof: per query base the substitution cost against each
+// target code, the insertion cost, the deletion cost by target code; taken within +-127) instead of matrix, ins, del:
+// GuidedAlign(..., idsScoreFn, ...) of /root/reference/iblasr/BlasrUtilsImpl.hpp:705-717.  A row's eleven values are
+// fetched one row ahead by eleven lanes and handed round through LDS.  The deletion cost now differs from column to
+// column, so the cost of reaching column k from column j along the row is P(k) - P(j) with P the prefix sum of the
+// row's deletion costs (one more wave scan per chunk), where the fixed cost had (k - j) * del.
+template <int NB, bool QV = false>
 __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t cls)
 {
+    __shared__ int32_t ptab[16];
     constexpr int WIDE_NB = NB;
     constexpr int WIDE_SBUF = NB == 1 ? WN_SBUF : ::WIDE_SBUF;
     __shared__ uint32_t ring[NB == 1 ? WN_RING : WIDE_RING];
@@ -943,8 +952,14 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t 
     const int32_t codeL = fc.cL - D;                    // arrow code of a deletion (<< 3)
     uint32_t spos = 0, sload = 0;                       // guide words consumed / loaded
     uint32_t W = 0, Wp = 0, dsh = 0, roff = 0;
+    const int16_t *prow = QV ? d.prof + (d.q_off[p] + d.qS[p]) * 11 : nullptr;      // row r >= 1 uses prow[(r - 1) * 11 ..]
+    int32_t pnext = QV && Q >= 1u && lane < 11 ? (int32_t)prow[lane] : 0;
     __syncthreads();
     for (uint32_t r = 0; r <= Q; r++) {
+        if constexpr (QV) {
+            if (lane < 11) ptab[lane] = min(max(pnext, -127), 127);              // read after the barriers below
+            if (r + 1u <= Q && r >= 1u && lane < 11) pnext = (int32_t)prow[(size_t)r * 11 + lane];
+        }
         // keep at least half the buffer's worth of guide words buffered (or everything that is left)
         while (sload - spos < (uint32_t)WIDE_SBUF / 2 && sload < wcap) {
             const uint32_t x = sload + lane;
@@ -980,7 +995,7 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t 
         // independent of each other; only the carries (scalar) link a chunk to the one before it
         for (uint32_t c0 = 0; c0 < W; c0 += 64 * WIDE_NB) {
             uint32_t up[WIDE_NB];
-            int32_t xv[WIDE_NB], incl[WIDE_NB];
+            int32_t xv[WIDE_NB], incl[WIDE_NB], pd[WIDE_NB];
 #pragma unroll
             for (int b = 0; b < WIDE_NB; b++) up[b] = ring[c0 + 64 * b + lane + dsh];     // past the row end: slots that exist, values nobody uses
             __syncthreads();                            // every lane has read its slots before any is overwritten
@@ -989,21 +1004,32 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t 
                 const uint32_t diag = (uint32_t)__builtin_amdgcn_update_dpp((int32_t)cdiag, (int32_t)up[b], 0x138, 0xf, 0xf, false);
                 cdiag = (uint32_t)__builtin_amdgcn_readlane((int32_t)up[b], 63);
                 const uint32_t tcd = up[b] & 7u;
-                const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);
-                const int32_t m = (int32_t)((sb << 5) + diag);
-                const int32_t u = (int32_t)up[b] + fc.cU;
-                xv[b] = min(m, u);                      // best of the two moves from the previous row
-                incl[b] = wave_scan_min((int32_t)((uint32_t)xv[b] & ~TAGS) - lane * D, BIG);
+                if constexpr (QV) {
+                    const uint32_t ti = min(max(tcd, 1u), 5u) - 1u;
+                    const int32_t subc = ptab[ti], insc = ptab[5], delc = r == 0u ? fc.del : ptab[6 + ti];
+                    const int32_t m = (int32_t)(((uint32_t)(subc + 128) << 5) + diag);
+                    const int32_t u = (int32_t)up[b] + fc.cU + (insc - fc.ins) * 32;
+                    xv[b] = min(m, u);
+                    pd[b] = (int32_t)wave_scan_sum((uint32_t)(delc * 32));          // P(k): the row's deletion costs up to and including column k of the chunk
+                    incl[b] = wave_scan_min((int32_t)((uint32_t)xv[b] & ~TAGS) - pd[b], BIG);
+                } else {
+                    const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);
+                    const int32_t m = (int32_t)((sb << 5) + diag);
+                    const int32_t u = (int32_t)up[b] + fc.cU;
+                    xv[b] = min(m, u);                      // best of the two moves from the previous row
+                    incl[b] = wave_scan_min((int32_t)((uint32_t)xv[b] & ~TAGS) - lane * D, BIG);
+                }
             }
 #pragma unroll
             for (int b = 0; b < WIDE_NB; b++) {
                 if (c0 + 64 * b < W) {
                     const int32_t excl = __builtin_amdgcn_update_dpp(BIG, incl[b], 0x138, 0xf, 0xf, false);
-                    const int32_t lc = min(excl + lane * D, hc + (lane + 1) * D) + codeL;
+                    const int32_t lc = (QV ? min(excl, hc) + pd[b] : min(excl + lane * D, hc + (lane + 1) * D)) + codeL;
                     const uint32_t best = (uint32_t)min(xv[b], lc);
                     ring[c0 + 64 * b + lane] = (up[b] & TAGS) | (best & ~TAGS);
                     // score of the chunk's last column: its own best over this chunk's columns, or the carry
-                    hc = min(__builtin_amdgcn_readlane(incl[b], 63) + 63 * D, hc + 64 * D);
+                    if constexpr (QV) hc = min(__builtin_amdgcn_readlane(incl[b], 63), hc) + __builtin_amdgcn_readlane(pd[b], 63);
+                    else hc = min(__builtin_amdgcn_readlane(incl[b], 63) + 63 * D, hc + 64 * D);
                     // arrows: 2 bits per column, 16 columns per dword
                     int32_t ab = (int32_t)(((best >> 3) & 3u) << (2 * (lane & 15)));
                     ab |= __builtin_amdgcn_update_dpp(0, ab, 0x111, 0xf, 0xf, false);
@@ -2182,6 +2208,7 @@ struct gba_ctx {
     // host-buffer batches: device copies of the caller's batch, the copy streams, the worker thread
     Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res, s_cigoff, s_gout;
     Buf s_qpk;                       // host-buffer batches with packed reads: the packed bytes as they arrive
+    Buf s_prof;                      // host-buffer batches with a quality-value profile: its device copy
     Buf kb[9];                       // gba_kband: band widths, strand flags, cost profile, arrow offsets, matrix, arrows, block slots, counts, offsets
     hipStream_t s_in = nullptr, s_out = nullptr;     // host-to-device and device-to-host copies, beside the kernels
     std::vector<hipEvent_t> ev_in;                   // per part: its inputs have arrived
@@ -2303,7 +2330,7 @@ int phase_guide(gba_ctx *c, Slot &sl, Dev &d)
     // times the instructions per cell but fill the GPU from a few thousand pairs on.  Below wave_pairs
     // pairs the whole batch runs one wave per pair.
     const bool affine = sc.mode == GBA_MODE_AFFINE;
-    const int lane_classes = d.n < (affine ? c->wave_pairs_affine : c->wave_pairs) ? 0
+    const int lane_classes = d.prof || d.n < (affine ? c->wave_pairs_affine : c->wave_pairs) ? 0      // quality-value costs: the wave-per-pair kernels have them
                            : affine ? (c->affine_top_slots ? LANE_CLS_AFFINE + 1 : LANE_CLS_AFFINE) : LANE_CLS_LINEAR;
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(SCAN_T), 0, sl.s, d, lane_classes, 1, affine ? c->affine_top_slots : 128u);
     HIPCHK(c, hipGetLastError());
@@ -2364,9 +2391,11 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
         if (wave) {
             if (k == CLS_WIDE) {
                 if (aff) hipLaunchKernelGGL(k_fill_wide_affine<false>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+                else if (d.prof) hipLaunchKernelGGL((k_fill_wide<4, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else hipLaunchKernelGGL(k_fill_wide<4>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
             } else {
                 if (aff) hipLaunchKernelGGL(k_fill_wide_affine<true>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+                else if (d.prof) hipLaunchKernelGGL((k_fill_wide<1, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else hipLaunchKernelGGL(k_fill_wide<1>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
             }
             HIPCHK(c, hipGetLastError());
@@ -2593,6 +2622,8 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
     g.q_off = b->q_off; g.t_off = b->t_off; g.blk_off = b->blk_off;
     g.q_len = b->q_len; g.t_len = b->t_len; g.n_blk = b->n_blk;
     g.guide_status = c->cur_guide_status;
+    g.prof = b->q_profile;
+    if (g.prof && c->sc.mode == GBA_MODE_AFFINE) return GBA_E_UNSUPPORTED;
     g.status = (int32_t *)c->b_pair32[0].ptr;
     g.qS = (uint32_t *)c->b_pair32[1].ptr; g.tS = (uint32_t *)c->b_pair32[2].ptr;
     g.Q = (uint32_t *)c->b_pair32[3].ptr; g.T = (uint32_t *)c->b_pair32[4].ptr;
@@ -2946,6 +2977,7 @@ void gba_destroy(gba_ctx *c)
     for (Buf *b : bs) release(*b);
     for (auto &b : c->kb) release(b);
     release(c->s_qpk);
+    release(c->s_prof);
     if (c->h_needed) (void)hipHostFree(c->h_needed);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (int h = 0; h < NSLOT; h++) {
@@ -3025,7 +3057,7 @@ int gba_set_scoring(gba_ctx *c, const gba_scoring *s)
     }
     f.cU = s->ins * (1 << SH) + (int32_t)(codeU << 3) + bias;
     f.cL = s->del * (1 << SH) + (int32_t)(codeL << 3);
-    f.del = s->del;
+    f.del = s->del; f.ins = s->ins;
     TbConst &t = c->tbc;
     for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) t.sub[a * 5 + b] = s->sub[a][b];
     t.ins = s->stats_ins; t.del = s->stats_del; t.aopen = s->stats_affine_open; t.aext = s->stats_affine_extend;
@@ -3103,12 +3135,19 @@ static int run_host_batch(gba_ctx *c, const gba_batch *b, gba_results *out)
         {&c->s_qoff, (size_t)n * 8}, {&c->s_toff, (size_t)n * 8}, {&c->s_boff, (size_t)n * 8},
         {&c->s_qlen, (size_t)n * 4}, {&c->s_tlen, (size_t)n * 4}, {&c->s_nblk, (size_t)n * 4},
         {&c->s_trc, b->t_rc ? (size_t)n : 0}, {&c->s_res, (size_t)n * sizeof(gba_pair_result)},
-        {&c->s_cigoff, cig ? ((size_t)n + 1) * 8 : 0}, {&c->s_qpk, b->q_packed ? (size_t)b->q_arena_bytes / 4 + 16 : 0}};
+        {&c->s_cigoff, cig ? ((size_t)n + 1) * 8 : 0}, {&c->s_qpk, b->q_packed ? (size_t)b->q_arena_bytes / 4 + 16 : 0},
+        {&c->s_prof, b->q_profile ? (size_t)b->q_arena_bytes * 22 : 0}};
     for (auto &x : need) if ((rc = ensure(c, *x.buf, x.bytes + 16))) return rc;
     gba_batch db = *b;
     db.q_arena = (const uint8_t *)c->s_q.ptr; db.t_arena = b->t_arena ? (const uint8_t *)c->s_t.ptr : nullptr;
     db.t_rc = b->t_rc ? (const uint8_t *)c->s_trc.ptr : nullptr;
     db.blocks = (const gba_block *)c->s_blk.ptr;
+    if (b->q_profile) {
+        // the profile goes first on the stream of the input copies: every part's "inputs have arrived" event follows it
+        if (c->sc.mode == GBA_MODE_AFFINE) return GBA_E_UNSUPPORTED;
+        HIPCHK(c, hipMemcpyAsync(c->s_prof.ptr, b->q_profile, (size_t)b->q_arena_bytes * 22, hipMemcpyHostToDevice, c->s_in));
+        db.q_profile = (const int16_t *)c->s_prof.ptr;
+    }
     db.q_off = (const uint64_t *)c->s_qoff.ptr; db.t_off = (const uint64_t *)c->s_toff.ptr;
     db.blk_off = (const uint64_t *)c->s_boff.ptr;
     db.q_len = (const uint32_t *)c->s_qlen.ptr; db.t_len = (const uint32_t *)c->s_tlen.ptr;

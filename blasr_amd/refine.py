@@ -44,6 +44,7 @@ class MappingParameters:
     sdpMaxFragments: int = 1024   # not a BLASR option: the device's budget of maximal matches per candidate
     sdpBypassThreshold: float = 1000000.0   # :340 (0.75 in the -sdpbypass preset, :721)
     scoreMatrix: Optional[list] = None     # 5x5, -scoreMatrix (Blasr.cpp:922-937)
+    ignoreQualities: bool = True           # :285; -useQuality turns it off
 
 
 @dataclass
@@ -318,24 +319,36 @@ def GuidedAlignFromSequences(read: bytes, cands: List[AlignmentCandidate], param
     return RefineAlignments(read, cands, p, ctx)
 
 
-def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx, want_blocks: bool = True):
+def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx, want_blocks: bool = True, qv=None):
     """Batched RefineAlignments (:905-923): all candidates of the read in one submit.
     want_blocks False: for interval / summary output (printFormat Interval, SummaryPrint, :992-1000), which
-    prints only what the pair results hold: no block leaves the device."""
+    prints only what the pair results hold: no block leaves the device.
+    qv: the read's QualityValues.  With params.ignoreQualities off and meaningful quality values the guided DP runs with
+    the IDS scorer (GuidedAlign(qSeq, tSeq, alignmentCandidate, idsScoreFn, params.guidedAlignBandSize, ...), :705-717):
+    its costs travel as gba_batch.q_profile (ids_profile).  AffineGuidedAlign with the IDS scorer (:707-710) is not on the
+    device: NotImplementedError."""
     if not params.refineAlignments or not cands:
         return cands
+    use_qv = qv is not None and not params.ignoreQualities and ReadHasMeaningfulQualityValues(qv)
     if params.doGlobalAlignment:
-        refine_global(read, cands, params, ctx)
+        if use_qv:
+            refine_global_qv(read, cands, params, ctx, qv)
+        else:
+            refine_global(read, cands, params, ctx)
         if params.sortRefinedAlignments:
             cands.sort(key=lambda c: c.score)
         return cands
     if not params.useGuidedAlign:
-        refine_legacy(read, cands, params, ctx)
+        refine_legacy(read, cands, params, ctx, qv if use_qv else None)
         if params.sortRefinedAlignments:
             cands.sort(key=lambda c: c.score)
         return cands
+    if use_qv and params.affineAlign:
+        raise NotImplementedError("AffineGuidedAlign with the IDS scorer (:707-710) is not on the accelerated path")
     ctx.set_scoring(scoring_from_params(params))
     batch = build_batch(read, cands)
+    if use_qv:
+        batch["q_profile"] = ids_profile(read, qv, params)
     if want_blocks:
         pairs, blocks, rc = ctx.refine_host(batch)
     else:

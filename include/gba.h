@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GBA_VERSION 360   /* major*10000 + minor*100 + patch */
+#define GBA_VERSION 370   /* major*10000 + minor*100 + patch */
 
 /* return codes of the entry points */
 enum {
@@ -137,6 +137,16 @@ typedef struct {
                                    other letters cannot be packed: send that batch as letters).  q_off, q_len and q_arena_bytes
                                    still count BASES; the packed arena holds ((q_arena_bytes + 15) / 16) * 4 bytes.  A quarter
                                    of the bytes cross the link; the device spells the letters out again as each part arrives. */
+    const int16_t *q_profile;   /* NULL, or the costs of a quality-value scorer in place of matrix, ins and del for the DP of this
+                                   batch: GuidedAlign(qSeq, tSeq, alignmentCandidate, idsScoreFn, band, ...) of
+                                   iblasr/BlasrUtilsImpl.hpp:705-717 (linear gaps; GBA_E_UNSUPPORTED with GBA_MODE_AFFINE).
+                                   11 values per base of q_arena (per BASE when the reads are packed), for the base at arena
+                                   position x: q_profile[11 x + c] = Match against target code c (A, C, G, T, N),
+                                   q_profile[11 x + 5] = Insertion of the base, q_profile[11 x + 6 + c] = Deletion of a
+                                   target base of code c behind it; each taken within +-127.  Deletions in front of the first
+                                   query base cost gba_scoring.del.  The rescoring (stats_*, extra[]) is unchanged.  Host
+                                   pointer for gba_submit (copied whole before the first part), device pointer for
+                                   gba_submit_device / _noalloc.  Such batches run on the wave-per-pair kernels. */
 } gba_batch;
 
 /* what RefineAlignment copies back into the candidate (BlasrUtilsImpl.hpp:745-772) */

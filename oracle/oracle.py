@@ -67,6 +67,7 @@ def lib():
             build()
         _lib = C.CDLL(_SO)
         _lib.gbo_align.restype = C.c_int
+        _lib.gbo_align_qv.restype = C.c_int
         _lib.gbo_guide_rows.restype = C.c_int
         _lib.gbo_full_dp_score.restype = C.c_int
         _lib.gbo_align_batch.restype = C.c_int
@@ -299,3 +300,20 @@ def kband_full_dp(q, t, params):
     lib().kbo_full_dp(q.ctypes.data_as(C.c_void_p), C.c_uint32(len(q)), t.ctypes.data_as(C.c_void_p), C.c_uint32(len(t)),
                       C.byref(params), C.byref(s))
     return s.value
+
+
+def align_qv(q, t, blocks, params, profile, blk_cap=None):
+    """One pair through gbo_align_qv: the guided DP with the costs of a quality-value scorer (profile: int16,
+    11 per base of q).  Returns (result dict, blocks)."""
+    q, t = _u8(q), _u8(t)
+    blk = _blocks(blocks)
+    cap = int(blk_cap if blk_cap is not None else len(q) + 1)
+    out = np.zeros(max(cap, 1), dtype=BLOCK_DT)
+    res = Result()
+    prof = np.ascontiguousarray(profile, dtype=np.int16)
+    assert len(prof) == 11 * len(q)
+    lib().gbo_align_qv(q.ctypes.data_as(C.c_void_p), C.c_uint32(len(q)), t.ctypes.data_as(C.c_void_p), C.c_uint32(len(t)),
+                       blk.ctypes.data_as(C.c_void_p), C.c_int(len(blk)), C.byref(params), prof.ctypes.data_as(C.c_void_p),
+                       out.ctypes.data_as(C.c_void_p), C.c_uint32(cap), C.byref(res))
+    d = {f[0]: getattr(res, f[0]) for f in Result._fields_}
+    return d, out[:min(d["n_blk"], cap)].copy()

@@ -8,7 +8,8 @@ Every second round also asks the device for the CIGAR operations (random flags) 
 sample of pairs with blasr_amd.emit.cigar_ops on the returned blocks; every third round runs the
 guide producer (gba_sdp, random tuple size / penalties / fragment budget) on the round's sequences
 against oracle/sdp_oracle.c; every third round runs the fixed-band aligners (gba_kband: random type, gap model, costs,
-bands, strand flags, cost profile) on a sample of the round's sequences against oracle/kband_oracle.c.
+bands, strand flags, cost profile) on a sample of the round's sequences against oracle/kband_oracle.c; every fourth round
+repeats the batch with the costs of a quality-value scorer (gba_batch.q_profile) against gbo_align_qv.
 Mismatches are written to gpurun_out/fuzz_fail_<k>.json with everything needed to replay them.
 
 usage: python tests/fuzz_gpu.py [--seconds 120] [--seed 1]
@@ -196,6 +197,48 @@ def check_kband(rng, api, oracle, _lib, ctx, pool, batch):
     return None, kw
 
 
+def check_qv(rng, api, oracle, _lib, ctx, pool, batch, kw):
+    """The round's batch again with the costs of a quality-value scorer (gba_batch.q_profile, random values, some outside
+    +-127) against gbo_align_qv.  Linear gaps and the k-band geometry only."""
+    n = int(batch["n_pairs"])
+    na = len(batch["q_arena"])
+    prof = rng.integers(-20, 60, (na, 11)).astype(np.int16)
+    wild = rng.random(na) < 0.01
+    prof[wild, int(rng.integers(0, 11))] = int(rng.choice([-400, 500]))
+    prof = prof.reshape(-1)
+    pairs, blocks, rc = ctx.refine_host(dict(batch, q_profile=prof))
+    if rc != 0:
+        return (0, "qv_rc", 0, rc)
+    P = oracle.make_params(**kw)
+
+    def one(p):
+        qo, ql = int(batch["q_off"][p]), int(batch["q_len"][p])
+        to, tl = int(batch["t_off"][p]), int(batch["t_len"][p])
+        bo, nb = int(batch["blk_off"][p]), int(batch["n_blk"][p])
+        if qo + ql > na or to + tl > len(batch["t_arena"]):
+            return None
+        return oracle.align_qv(batch["q_arena"][qo:qo + ql], batch["t_arena"][to:to + tl], batch["blocks"][bo:bo + nb], P, prof[qo * 11:(qo + ql) * 11])
+    want = list(pool.map(one, range(n)))
+    for p in range(n):
+        if want[p] is None:
+            continue
+        w, wb = want[p]
+        g = pairs[p]
+        if int(g["status"]) in (_lib.PAIR_TOO_WIDE, _lib.PAIR_TOO_LONG):
+            continue
+        if int(g["status"]) != w["status"]:
+            return (p, "qv_status", w["status"], int(g["status"]))
+        if w["status"] != 0:
+            continue
+        for fld in FIELDS:
+            if int(g[fld]) != int(w[fld]):
+                return (p, "qv_" + fld, int(w[fld]), int(g[fld]))
+        kb = blocks[int(g["blk_off"]):int(g["blk_off"]) + int(g["n_blk"])]
+        if len(kb) != len(wb) or not (kb == wb).all():
+            return (p, "qv_blocks", len(wb), len(kb))
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
@@ -208,7 +251,7 @@ def main():
     ctx = api.Context(0)
     pool = ThreadPoolExecutor(16)
     t_end = time.time() + args.seconds
-    rounds = pairs_done = fails = unsupported = cigar_rounds = sdp_rounds = kband_rounds = 0
+    rounds = pairs_done = fails = unsupported = cigar_rounds = sdp_rounds = kband_rounds = qv_rounds = 0
     hist = {}
     modes = {}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -279,6 +322,9 @@ def main():
             sdp_rounds += 1
             if bad:
                 kw = dict(kw, sdp=skw)
+        if not bad and rounds % 4 == 3 and kw["mode"] != _lib.MODE_AFFINE:
+            bad = check_qv(rng, api, oracle, _lib, ctx, pool, batch, kw)
+            qv_rounds += 1
         if not bad and rounds % 3 == 1:
             bad, kkw = check_kband(rng, api, oracle, _lib, ctx, pool, batch)
             kband_rounds += 1
@@ -306,7 +352,7 @@ def main():
         if rounds % 20 == 0:
             print("rounds %d pairs %d fails %d unsupported-scoring %d" % (rounds, pairs_done, fails, unsupported), flush=True)
     print("DONE rounds %d pairs %d fails %d unsupported-scoring %d" % (rounds, pairs_done, fails, unsupported), flush=True)
-    print("status histogram", hist, "pairs per mode", modes, "rounds with CIGAR check", cigar_rounds, "rounds with guide production", sdp_rounds, "rounds with fixed-band aligners", kband_rounds, flush=True)
+    print("status histogram", hist, "pairs per mode", modes, "rounds with CIGAR check", cigar_rounds, "rounds with guide production", sdp_rounds, "rounds with fixed-band aligners", kband_rounds, "rounds with quality-value costs", qv_rounds, flush=True)
     sys.exit(1 if fails else 0)
 
 

@@ -1,0 +1,124 @@
+"""Quality-value costs inside the guided DP (gba_batch.q_profile: GuidedAlign with the IDS scorer,
+/root/reference/iblasr/BlasrUtilsImpl.hpp:705-717), through the C-ABI against oracle/gba_oracle.c's
+gbo_align_qv, bit for bit: host and device batches, narrow and wide bands, the k-band geometry, packed reads."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _profile(rng, batch):
+    """Random costs for every byte of the query arena, a few of them outside the +-127 the kernels take."""
+    n = len(batch["q_arena"])
+    p = np.zeros((n, 11), np.int16)
+    p[:, :5] = rng.integers(1, 40, (n, 5))
+    code = np.full(256, 4, np.int64)
+    for i, c in enumerate(b"ACGT"):
+        code[c] = i; code[c + 32] = i
+    p[np.arange(n), code[batch["q_arena"]]] = rng.integers(-9, 1, n)
+    p[:, 5] = rng.integers(0, 25, n)
+    p[:, 6:] = rng.integers(0, 25, (n, 5))
+    wild = rng.random(n) < 0.01
+    p[wild, 5] = 300
+    p[wild, 7] = -200
+    return p.reshape(-1)
+
+
+def _check(oracle, batch, prof, OP, pairs, blocks):
+    n = int(batch["n_pairs"])
+    from blasr_amd import synth
+    for p in range(n):
+        q, t, blk = synth.pair(batch, p)
+        o = int(batch["q_off"][p])
+        want, wb = oracle.align_qv(q, t, blk, OP, prof[o * 11:(o + len(q)) * 11])
+        g = pairs[p]
+        assert int(g["status"]) == want["status"], (p, int(g["status"]), want["status"])
+        if want["status"] != 0:
+            continue
+        for f in util.FIELDS:
+            assert int(g[f]) == int(want[f]), (f, p, int(g[f]), int(want[f]))
+        kb = blocks[int(g["blk_off"]):int(g["blk_off"]) + int(g["n_blk"])]
+        assert (kb == wb).all(), p
+
+
+@pytest.mark.parametrize("band", [10, 120])
+@pytest.mark.parametrize("tie", [0, 1])
+def test_profile_costs_in_the_guided_dp(oracle, synth, band, tie):
+    import torch
+    from blasr_amd import api, _lib
+    rng = np.random.default_rng(5 + band + tie)
+    batch = synth.compact_blocks(synth.generate(160, read_len=900, len_jitter=500, seed=31 + band))
+    prof = _profile(rng, batch)
+    kw = dict(band=band, tie_break=tie, ins=5, dele=4)
+    ctx = api.Context(0)
+    ctx.set_scoring(api.make_scoring(**kw))
+    OP = oracle.make_params(**kw)
+    with_prof = dict(batch, q_profile=prof)
+    pairs, blocks, rc = ctx.refine_host(with_prof)
+    assert rc == 0 and int((pairs["status"] == 0).sum()) == 160
+    _check(oracle, batch, prof, OP, pairs, blocks)
+    # the costs matter: the same batch without them scores differently
+    plain, _, _ = ctx.refine_host(batch)
+    assert (plain["dp_score"] != pairs["dp_score"]).any()
+    # device-resident batch, and the reads 2 bits per base
+    d = api.to_device(with_prof)
+    out_pairs = torch.zeros(160 * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0")
+    out_blocks = torch.zeros((len(blocks) + 8, 3), dtype=torch.int32, device="cuda:0")
+    rc, needed = ctx.refine_device(d, out_pairs, out_blocks)
+    torch.cuda.synchronize()
+    assert rc == 0 and out_pairs.cpu().numpy().view(_lib.PAIR_RESULT_DT).tobytes() == pairs.tobytes()
+    pk = api.pack_reads_2bit(batch)
+    pk["q_profile"] = prof
+    p2, b2, rc = ctx.refine_host(pk)
+    assert rc == 0 and p2.tobytes() == pairs.tobytes() and b2.tobytes() == blocks.tobytes()
+    ctx.close()
+
+
+def test_profile_with_the_kband_geometry_and_refusal_with_affine_gaps(oracle, synth):
+    from blasr_amd import api, _lib
+    rng = np.random.default_rng(2)
+    batch = synth.compact_blocks(synth.generate(40, read_len=500, len_jitter=100, seed=9))
+    prof = _profile(rng, batch)
+    kw = dict(mode=_lib.MODE_KBAND, kband_k=150, ins=6, dele=6)
+    ctx = api.Context(0)
+    ctx.set_scoring(api.make_scoring(**kw))
+    pairs, blocks, rc = ctx.refine_host(dict(batch, q_profile=prof))
+    assert rc == 0
+    _check(oracle, batch, prof, oracle.make_params(**kw), pairs, blocks)
+    ctx.set_scoring(api.make_scoring(mode=_lib.MODE_AFFINE, band=16))
+    ctx.submit_host(dict(batch, q_profile=prof), np.zeros(40, _lib.PAIR_RESULT_DT), np.zeros(40 * 600, _lib.BLOCK_DT))
+    with pytest.raises(api.GbaError) as e:
+        ctx.wait_host()
+    assert e.value.code == _lib.E_UNSUPPORTED
+    ctx.close()
+
+
+def test_refine_alignments_with_quality_values(oracle, synth):
+    """refine.RefineAlignments(..., qv=...) with -useQuality: the IDS scorer's costs (refine.ids_profile) drive the
+    guided DP; against the oracle on the same slices and costs."""
+    from blasr_amd import api, refine
+    rng = np.random.default_rng(11)
+    batch = synth.generate(6, read_len=700, len_jitter=200, seed=123)
+    ctx = api.Context(0)
+    params = refine.MappingParameters(ignoreQualities=False)
+    ACGT = np.frombuffer(b"ACGT", np.uint8)
+    for i in range(6):
+        q, t, blk = synth.pair(batch, i)
+        read, n = bytes(q), len(q)
+        qv = refine.QualityValues(qual=bytes(rng.integers(1, 40, n, dtype=np.uint8)), insertionQV=bytes(rng.integers(1, 20, n, dtype=np.uint8)),
+                                  deletionQV=bytes(rng.integers(1, 20, n, dtype=np.uint8)), deletionTag=rng.choice(np.frombuffer(b"ACGTN", np.uint8), n).tobytes(),
+                                  substitutionQV=bytes(rng.integers(1, 30, n, dtype=np.uint8)), substitutionTag=rng.choice(ACGT, n).tobytes())
+        q0, t0 = int(blk[0]["q_pos"]), int(blk[0]["t_pos"])
+        rel = blk.copy(); rel["q_pos"] -= np.uint32(q0); rel["t_pos"] -= np.uint32(t0)
+        c = refine.AlignmentCandidate(tAlignedSeq=bytes(t), qPos=q0, tPos=t0, blocks=rel)
+        refine.RefineAlignments(read, [c], params, ctx, qv=qv)
+        ql = int(rel[-1]["q_pos"]) + int(rel[-1]["length"]); tl = int(rel[-1]["t_pos"]) + int(rel[-1]["length"])
+        prof = refine.ids_profile(read, qv, params)
+        OP = oracle.make_params(ins=params.deletion, dele=params.insertion, indel=params.indel, band=params.guidedAlignBandSize)
+        want, wb = oracle.align_qv(read[q0:q0 + ql], bytes(t)[t0:t0 + tl], rel, OP, prof[q0 * 11:(q0 + ql) * 11])
+        assert c.status == 0 and want["status"] == 0
+        assert (c.score, c.nCells, c.nMatch, len(c.blocks)) == (want["score"], want["ncells"], want["n_match"], want["n_blk"])
+        assert (c.blocks == wb).all()
+    ctx.close()
