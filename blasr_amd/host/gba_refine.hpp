@@ -158,15 +158,55 @@ inline std::string CigarString(const AlignmentCandidate &c, bool cigarUseSeqMatc
     return out;
 }
 
+// The per-base fields of a FASTQSequence the QV-aware scorers read (empty string = absent vector).
+struct QualityValues { std::string qual, insertionQV, deletionQV, deletionTag, substitutionQV, substitutionTag; };
+
+// IDSScoreFunction as RefineAlignment sets it up (:636-646), evaluated per query base into the 11 costs gba takes
+// (see gba.h): Match = the matrix diagonal for equal bases, substitutionQV when the target base is the
+// substitutionTag, substitutionPrior otherwise; Insertion = insertionQV (params.insertion without);
+// Deletion = deletionQV when the target base is the deletionTag, globalDeletionPrior otherwise (params.deletion
+// without deletion QVs / tags).  The class is libcpp code absent from the reference tree: UNPINNED.
+inline std::vector<int16_t> IdsProfile(const std::string &read, const QualityValues &qv, const MappingParameters &p,
+                                       int substitutionPrior = 20, int globalDeletionPrior = 13)
+{
+    auto code = [](char c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } };
+    gba_scoring m{};
+    MatrixFromParams(p, m);
+    std::vector<int16_t> prof(11 * read.size());
+    const bool sub = qv.substitutionQV.size() == read.size() && qv.substitutionTag.size() == read.size();
+    const bool del = qv.deletionQV.size() == read.size() && qv.deletionTag.size() == read.size();
+    for (size_t i = 0; i < read.size(); i++) {
+        const int qc = code(read[i]);
+        for (int c = 0; c < 5; c++) {
+            int v = substitutionPrior;
+            if (sub && c < 4 && code(qv.substitutionTag[i]) == c) v = (uint8_t)qv.substitutionQV[i];
+            if (qc == c) v = m.sub[qc][qc];
+            prof[11 * i + c] = (int16_t)std::max(-1023, std::min(1023, v));
+            int d = p.deletion;
+            if (del) d = (c < 4 && qv.deletionTag[i] != 'N' && code(qv.deletionTag[i]) == c) ? (uint8_t)qv.deletionQV[i] : globalDeletionPrior;
+            prof[11 * i + 6 + c] = (int16_t)d;
+        }
+        prof[11 * i + 5] = (int16_t)(qv.insertionQV.size() == read.size() ? (uint8_t)qv.insertionQV[i] : p.insertion);
+    }
+    return prof;
+}
+
 // Collects (read, candidate) pairs of many reads, runs them as one batch.
 class RefineBatch {
 public:
     explicit RefineBatch(gba_ctx *ctx) : ctx_(ctx) {}
 
-    // slicing rules of :693-703; a candidate without blocks is kept with n_blk = 0 (:681)
-    void Add(const std::string &read, AlignmentCandidate *c)
+    // slicing rules of :693-703; a candidate without blocks is kept with n_blk = 0 (:681).
+    // profile (optional, all reads of a batch or none): the costs of the IDS scorer for this read, 11 per base
+    // (IdsProfile below): the batch then runs GuidedAlign with idsScoreFn (:713-716 with -useQuality).
+    void Add(const std::string &read, AlignmentCandidate *c, const std::vector<int16_t> *profile = nullptr)
     {
+        const size_t before = q_arena_.size();
         const uint64_t qbase = Intern(read);
+        if (profile) {
+            if (profile->size() != 11 * read.size()) throw std::invalid_argument("profile must hold 11 costs per base of the read");
+            if (q_arena_.size() != before) prof_.insert(prof_.end(), profile->begin(), profile->end());     // a newly interned read
+        }
         cands_.push_back(c);
         const size_t nb = c->blocks.size();
         if (nb == 0) {
@@ -203,6 +243,10 @@ public:
         b.t_arena = (const uint8_t *)t_arena_.data(); b.t_off = t_off_.data(); b.t_len = t_len_.data();
         b.blocks = blocks_.data(); b.blk_off = b_off_.data(); b.n_blk = n_blk_.data();
         b.q_arena_bytes = q_arena_.size(); b.t_arena_bytes = t_arena_.size(); b.n_blocks_total = blocks_.size();
+        if (!prof_.empty()) {
+            if (prof_.size() != 11 * q_arena_.size()) return GBA_E_INVALID;      // some reads came with a profile, some without
+            b.q_profile = prof_.data();
+        }
         uint64_t cap = n;
         for (uint32_t l : q_len_) cap += l;
         if (!wantBlocks) cap = 0;
@@ -252,6 +296,7 @@ private:
     std::vector<AlignmentCandidate *> cands_;
     std::string q_arena_, t_arena_;
     std::vector<gba_block> blocks_;
+    std::vector<int16_t> prof_;
     std::vector<uint64_t> q_off_, t_off_, b_off_;
     std::vector<uint32_t> q_len_, t_len_, n_blk_;
     bool have_last_ = false; size_t last_len_ = 0; uint64_t last_base_ = 0;

@@ -10,6 +10,8 @@
 //   sdp      the guides come from the device first (SDPAlignCandidates: the blocks of the input are ignored), then the batch
 //   fused    SDPAlign and RefineAlignment in one submit (AlignAndRefineCandidates; the blocks of the input are ignored)
 //   intervals  run without a block arena and print per candidate: status score nBlocks qStart qEnd tStart tEnd
+//   qv       every candidate line carries five more strings behind its blocks (insertionQV deletionQV deletionTag substitutionQV
+//            substitutionTag, quality values as letters: value + 33): the batch runs with the IDS scorer's costs (IdsProfile)
 //   legacy   run the branch without guided alignment (RefineLegacy: AffineKBandAlign in a band around the guide's drift)
 //   extend   stdin is n, the genome, then per candidate "read tAlignedSeqPos qAlignedSeqPos nblk blocks..." (its window is the
 //            genome from tAlignedSeqPos over the span of its blocks): the -extend step (ExtendAlignments); prints per candidate
@@ -78,11 +80,18 @@ int main(int argc, char **argv)
     }
     std::vector<std::string> reads(n);
     std::vector<gba::AlignmentCandidate> cands(n);
+    std::vector<gba::QualityValues> qvs;
     for (size_t i = 0; i < n; i++) {
         size_t nb;
         std::cin >> reads[i] >> cands[i].tAlignedSeq >> nb;
         cands[i].blocks.resize(nb);
         for (auto &b : cands[i].blocks) std::cin >> b.qPos >> b.tPos >> b.length;
+        if (mode == "qv") {
+            gba::QualityValues q;
+            std::cin >> q.insertionQV >> q.deletionQV >> q.deletionTag >> q.substitutionQV >> q.substitutionTag;
+            for (std::string *s : {&q.insertionQV, &q.deletionQV, &q.substitutionQV}) for (char &ch : *s) ch = (char)(ch - 33);
+            qvs.push_back(q);
+        }
     }
     gba_ctx *ctx = nullptr;
     gba_config cfg{0, 0, nullptr};
@@ -122,6 +131,7 @@ int main(int argc, char **argv)
         std::string buffer;
         for (size_t i = 0; i < n; i++) {
             if (reuse) { buffer.assign(reads[i]); batch.Add(buffer, &cands[i]); }
+            else if (mode == "qv") { const std::vector<int16_t> prof = gba::IdsProfile(reads[i], qvs[i], params); batch.Add(reads[i], &cands[i], &prof); }
             else batch.Add(reads[i], &cands[i]);
         }
         rc = batch.Run(params, !intervals);

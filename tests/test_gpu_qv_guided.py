@@ -122,3 +122,41 @@ def test_refine_alignments_with_quality_values(oracle, synth):
         assert (c.score, c.nCells, c.nMatch, len(c.blocks)) == (want["score"], want["ncells"], want["n_match"], want["n_blk"])
         assert (c.blocks == wb).all()
     ctx.close()
+
+
+def test_cpp_shim_with_quality_values(oracle, synth):
+    """refine_demo qv: gba::IdsProfile + RefineBatch::Add(read, cand, &profile) give what the Python mirror gives."""
+    import os
+    import subprocess
+    from blasr_amd import api, build, refine
+    exe = build.HOST_DEMO
+    assert os.path.exists(exe), "run python -m blasr_amd.build"
+    rng = np.random.default_rng(21)
+    batch = synth.generate(5, read_len=600, len_jitter=200, seed=55)
+    ctx = api.Context(0)
+    params = refine.MappingParameters(ignoreQualities=False, sortRefinedAlignments=False)
+    ACGT = np.frombuffer(b"ACGT", np.uint8)
+    lines, want = ["5"], []
+    enc = lambda b: bytes(x + 33 for x in b).decode()
+    for i in range(5):
+        q, t, blk = synth.pair(batch, i)
+        read, n = bytes(q), len(q)
+        q0, t0 = int(blk[0]["q_pos"]), int(blk[0]["t_pos"])
+        rd, tg = read[q0:], bytes(t)[t0:]            # the demo's candidates start at (0, 0)
+        n = len(rd)
+        qv = refine.QualityValues(qual=bytes(rng.integers(1, 40, n, dtype=np.uint8)), insertionQV=bytes(rng.integers(1, 20, n, dtype=np.uint8)),
+                                  deletionQV=bytes(rng.integers(1, 20, n, dtype=np.uint8)), deletionTag=rng.choice(np.frombuffer(b"ACGTN", np.uint8), n).tobytes(),
+                                  substitutionQV=bytes(rng.integers(1, 30, n, dtype=np.uint8)), substitutionTag=rng.choice(ACGT, n).tobytes())
+        rel = blk.copy(); rel["q_pos"] -= np.uint32(q0); rel["t_pos"] -= np.uint32(t0)
+        c = refine.AlignmentCandidate(tAlignedSeq=tg, blocks=rel.copy())
+        refine.RefineAlignments(rd, [c], params, ctx, qv=qv)
+        want.append(c)
+        lines.append("%s %s %d %s %s %s %s %s %s" % (rd.decode(), tg.decode(), len(rel), " ".join("%d %d %d" % tuple(int(v) for v in b) for b in rel),
+                                                      enc(qv.insertionQV), enc(qv.deletionQV), qv.deletionTag.decode(), enc(qv.substitutionQV), qv.substitutionTag.decode()))
+    out = subprocess.run([exe, "qv"], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    for row, c in zip(out.stdout.strip().split("\n"), want):
+        v = [int(x) for x in row.split()]
+        assert v[:6] == [c.status, c.score, c.nCells, c.qPos, c.tPos, len(c.blocks)]
+        assert v[6:] == [int(x) for b in c.blocks for x in b]
+    ctx.close()
