@@ -6,7 +6,11 @@ timeout -k 10 1000 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeou
 tail -2 gpurun_out/r02_final_gputests.log
 timeout -k 10 500 python bench.py > gpurun_out/r02_final_bench.json 2> gpurun_out/r02_final_bench.err || { tail -20 gpurun_out/r02_final_bench.err; exit 1; }
 cat gpurun_out/r02_final_bench.json
-bash tools/prof_bench.sh r02_finalprof --steps 2 --warmup 1 --no-host --no-guides > /dev/null || exit 1
-bash tools/pmc_bench.sh r02_final_sq "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_ANY SQ_INSTS_SALU" --steps 1 --warmup 0 --no-host --no-guides | grep -i "k_fill\|k_trace\|k_guide" || exit 1
-bash tools/pmc_bench.sh r02_final_wr "WRITE_SIZE" --steps 1 --warmup 0 --no-host --no-guides | grep -i "k_fill\|k_trace" || exit 1
-bash tools/pmc_bench.sh r02_final_rd "FETCH_SIZE" --steps 1 --warmup 0 --no-host --no-guides | grep -i "k_fill\|k_trace" || exit 1
+bash tools/prof_bench.sh r02_finalprof --steps 2 --warmup 1 --no-host --no-guides --no-fixed-band > /dev/null || exit 1
+bash tools/pmc_bench.sh r02_final_sq "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_ANY SQ_INSTS_SALU" --steps 1 --warmup 0 --no-host --no-guides --no-fixed-band | grep -i "k_fill\|k_trace\|k_guide" || exit 1
+bash tools/pmc_bench.sh r02_final_wr "WRITE_SIZE" --steps 1 --warmup 0 --no-host --no-guides --no-fixed-band | grep -i "k_fill\|k_trace" || exit 1
+bash tools/pmc_bench.sh r02_final_rd "FETCH_SIZE" --steps 1 --warmup 0 --no-host --no-guides --no-fixed-band | grep -i "k_fill\|k_trace" || exit 1
+timeout -k 10 300 python -u tools/kband_time.py > gpurun_out/r02_final_kband_time.log 2>&1 || exit 1
+grep -v amdgpu gpurun_out/r02_final_kband_time.log
+GBA_WAVE_PAIRS=1000000 timeout -k 10 300 python -u tools/qv_time.py > gpurun_out/r02_final_qv_time.log 2>&1 || exit 1
+grep -v amdgpu gpurun_out/r02_final_qv_time.log
