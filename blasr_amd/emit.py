@@ -110,3 +110,62 @@ def m4_line(cand, q_name: str, t_name: str, q_length: int, t_length: int, map_qv
     return "%s %s %d %g %d %d %d %d %d %d %d %d %d" % (
         q_name, t_name, cand.score, cand.pctSimilarity, q_strand, qs, qe, q_length,
         cand.tStrand, ts, te, t_length, map_qv)
+
+
+# ---- the record formats with the aligned strings: -m 5 (CompareSequencesParsable) and SAM
+
+_RC = bytes.maketrans(b"ACGTacgtNn", b"TGCAtgcaNn")
+
+
+def aligned_strings(blocks, q_seq: bytes, t_seq: bytes, q_pos: int = 0, t_pos: int = 0):
+    """(qAlignedSeq, matchPattern, tAlignedSeq) of a candidate from its first block to the end of its last:
+    '-' against a gap, query-only stretches of a gap before its target-only ones, '|' for equal bases
+    (case-insensitive) and '*' otherwise in the pattern, as `blasr -m 5` prints them."""
+    q, t = q_seq.decode("latin1"), t_seq.decode("latin1")
+    qs, ts = [], []
+    for b in range(len(blocks)):
+        bq, bt, ln = int(blocks[b]["q_pos"]) + q_pos, int(blocks[b]["t_pos"]) + t_pos, int(blocks[b]["length"])
+        qs.append(q[bq:bq + ln]); ts.append(t[bt:bt + ln])
+        if b + 1 < len(blocks):
+            nq, nt = int(blocks[b + 1]["q_pos"]) + q_pos, int(blocks[b + 1]["t_pos"]) + t_pos
+            qs.append(q[bq + ln:nq] + "-" * (nt - bt - ln)); ts.append("-" * (nq - bq - ln) + t[bt + ln:nt])
+    qa, ta = "".join(qs), "".join(ts)
+    pat = "".join("|" if a == b and a != "-" else "*" for a, b in zip(qa.upper(), ta.upper()))
+    return qa, pat, ta
+
+
+def m5_line(cand, q_name: str, t_name: str, q_length: int, t_length: int, map_qv: int = 254, q_strand: int = 0) -> str:
+    """One -m 5 record (printFormat CompareSequencesParsable, iblasr/RegisterBlasrOptions.h:276) of a refined
+    candidate that holds its blocks and aligned sequences: qName qLength qStart qEnd qStrand tName tLength tStart tEnd
+    tStrand score numMatch numMismatch numIns numDel mapQV qAlignedSeq matchPattern tAlignedSeq (layout from BLASR's
+    manual; the writer itself is libcpp code).  Coordinates as in m4_line; strands print as + / -."""
+    qs, qe, ts, te = aligned_interval(cand.blocks, cand.qAlignedSeqPos + cand.qPos, cand.tAlignedSeqPos + cand.tPos)
+    qa, pat, ta = aligned_strings(cand.blocks, cand.qAlignedSeq, cand.tAlignedSeq, cand.qPos, cand.tPos)
+    return " ".join(str(x) for x in (q_name, q_length, qs, qe, "-" if q_strand else "+", t_name, t_length, ts, te,
+                                     "-" if cand.tStrand else "+", cand.score, cand.nMatch, cand.nMismatch, cand.nIns, cand.nDel,
+                                     map_qv, qa, pat, ta))
+
+
+def sam_line(cand, q_name: str, t_name: str, read: bytes, t_length: int, map_qv: int = 254, use_seq_match: bool = False,
+             allow_adjacent_indels: bool = False, soft_clip: bool = True, edit_distance=None) -> str:
+    """One SAM record of a refined candidate (what SAMOutput::PrintAlignment makes of it, iblasr/BlasrUtilsImpl.hpp:969-971;
+    the writer is libcpp code: the eleven mandatory columns and AS / NM follow the SAM specification).  The read is the
+    forward read; a candidate on the reverse strand (tStrand 1: its window is the reverse complement of the reference)
+    is reported on the forward strand of the reference: flag 16, the read reverse-complemented, the CIGAR reversed, POS
+    counted from the window's far end.  t_length: length of the reference sequence the positions of a reverse-strand
+    candidate count along.  Unclipped read bases become soft clips (--clipping soft) or are left out (none)."""
+    qs, qe, ts, te = aligned_interval(cand.blocks, cand.qAlignedSeqPos + cand.qPos, cand.tAlignedSeqPos + cand.tPos)
+    ops = cigar_ops(cand.blocks, cand.qAlignedSeq, cand.tAlignedSeq, q_pos=cand.qPos, t_pos=cand.tPos,
+                    use_seq_match=use_seq_match, allow_adjacent_indels=allow_adjacent_indels,
+                    clip_left=qs if soft_clip else 0, clip_right=len(read) - qe if soft_clip else 0)
+    seq = read if soft_clip else read[qs:qe]
+    flag, pos = 0, ts + 1
+    if cand.tStrand:
+        flag, pos = 16, t_length - te + 1
+        ops = ops[::-1]
+        seq = seq.translate(_RC)[::-1]
+    tags = ["AS:i:%d" % cand.score]
+    if edit_distance is not None:
+        tags.append("NM:i:%d" % edit_distance)
+    return "\t".join([q_name, str(flag), t_name, str(pos), str(map_qv), "".join("%d%s" % o for o in ops), "*", "0", "0",
+                      seq.decode("latin1"), "*"] + tags)

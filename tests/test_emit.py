@@ -116,3 +116,38 @@ def test_m4_line():
     assert len(f) == 13
     assert f[:4] == ["m/1/0_100", "chr", "-420", "87.5"]
     assert [int(x) for x in f[4:]] == [0, 12, 110, 120, 1, 1003, 1110, 5000, 254]
+
+
+def test_m5_line_round_trips_through_the_ingest_hook_and_sam_is_consistent():
+    """emit.m5_line is parsed back by tests/ingest_goldens.py (the hook for real `blasr -m 5` output) into the same
+    blocks and counts; emit.sam_line agrees with it on lengths, strand and position."""
+    import re
+    import ingest_goldens as ig
+    from blasr_amd import emit, refine
+    read = b"TTACGTACGTAAGGCCTTACGATCGATTTGGA"
+    window = b"GGACGTACGTAAGCCTTACGAATCGATTTCC"
+    blk = np.zeros(3, refine.BLOCK_DT)
+    blk[0] = (0, 0, 11); blk[1] = (12, 11, 8); blk[2] = (20, 20, 8)       # one inserted read base, one deleted reference base
+    c = refine.AlignmentCandidate(tAlignedSeq=window[2:], qAlignedSeq=read[2:], tAlignedSeqPos=1002, qAlignedSeqPos=2, blocks=blk,
+                                  score=-111, nMatch=27, nMismatch=0, nIns=1, nDel=1)
+    line = emit.m5_line(c, "read/0", "ref", len(read), 5000, map_qv=30)
+    rec = ig.parse_m5(line)
+    assert rec is not None and (rec["qStart"], rec["qEnd"], rec["tStart"], rec["tEnd"]) == (2, 30, 1002, 1030)
+    q, t, blocks = ig.blocks_from_strings(rec["qAlignedSeq"], rec["tAlignedSeq"])
+    assert q == read[2:30] and t == window[2:30] and blocks == [(0, 0, 11), (12, 11, 8), (20, 20, 8)]
+    same = sum(read[2 + bq + i] == window[2 + bt + i] for bq, bt, ln in blocks for i in range(ln))
+    assert rec["matchPattern"].count("|") == same and rec["matchPattern"].count("*") == 27 - same + 2
+    assert (rec["numIns"], rec["numDel"], rec["score"], rec["mapQV"]) == (1, 1, -111, 30)
+    sam = emit.sam_line(c, "read/0", "ref", read, 5000, map_qv=30, use_seq_match=True, edit_distance=2).split("\t")
+    assert sam[1] == "0" and sam[3] == "1003" and sam[4] == "30" and sam[9] == read.decode()
+    ops = [(int(n), o) for n, o in re.findall(r"(\d+)([MIDS=X])", sam[5])]
+    assert [o for _, o in ops if o in "SID"] == ["S", "I", "D", "S"] and ops[0] == (2, "S") and ops[-1] == (2, "S")
+    assert sum(n for n, o in ops if o == "=") == same and sum(n for n, o in ops if o in "=X") == 27
+    assert sum(n for n, o in ops if o in "SI=XM") == len(read)
+    assert "AS:i:-111" in sam and "NM:i:2" in sam
+    # the same candidate on the reverse strand: flag 16, read reverse-complemented, CIGAR reversed, POS from the far end
+    c.tStrand = 1
+    rs = emit.sam_line(c, "read/0", "ref", read, 5000, use_seq_match=True).split("\t")
+    assert rs[1] == "16" and rs[3] == str(5000 - 1030 + 1)
+    assert [(int(n), o) for n, o in re.findall(r"(\d+)([MIDS=X])", rs[5])] == ops[::-1]
+    assert rs[9] == read.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1].decode()
