@@ -175,3 +175,25 @@ def test_golden_fixture_through_the_library(api, oracle):
             assert int(got[0][f_]) == c["result"][f_], (c["set"], f_)
         assert [[int(x["q_pos"]), int(x["t_pos"]), int(x["length"])] for x in blocks] == c["blocks"], c["set"]
     ctx.close()
+
+
+def test_full_length_pairs(api, oracle):
+    """Reads of 10 kb in a band of 60 with a cost profile, and one pair of 50 kb in the widest band (k = 250)."""
+    from blasr_amd import _lib
+    rng = np.random.default_rng(77)
+    ctx = api.Context(0)
+    from kband_cases import ACGT, _read
+    pairs = []
+    for _ in range(6):              # 6 % errors: the lengths differ by about 100, inside the kernels' widest band of 255
+        t = rng.choice(ACGT, int(rng.integers(9000, 10001))).astype(np.uint8)
+        pairs.append((_read(rng, t, 0.06, False), t))
+    ks = [max(60, abs(len(q) - len(t)) + 20) for q, t in pairs]
+    assert max(ks) <= 255
+    prof = random_profile(rng, pairs)
+    _run_and_compare(api, oracle, ctx, pairs, ks, api.make_kband_params(align_type=_lib.KB_GLOBAL, ins=6, dele=6), profile=prof)
+    tb = rng.choice(ACGT, 50000).astype(np.uint8)
+    big = [(_read(rng, tb, 0.02, False), tb)]
+    if abs(len(big[0][0]) - len(big[0][1])) <= 250:
+        got = _run_and_compare(api, oracle, ctx, big, [250], api.make_kband_params(align_type=_lib.KB_GLOBAL, gap_model=_lib.KB_AFFINE_HP))
+        assert int(got[0]["status"]) == 0 and int(got[0]["rows"]) == len(big[0][0])
+    ctx.close()
