@@ -160,3 +160,40 @@ def test_cpp_shim_with_quality_values(oracle, synth):
         assert v[:6] == [c.status, c.score, c.nCells, c.qPos, c.tPos, len(c.blocks)]
         assert v[6:] == [int(x) for b in c.blocks for x in b]
     ctx.close()
+
+
+def test_a_profile_that_spells_out_the_matrix_gives_the_plain_results(synth, monkeypatch):
+    """Size-independent property at the benchmark's read length: a profile whose costs are the matrix row of each
+    base, ins and del reproduces, on the wave-per-pair kernels with the prefix-sum deletion chain, exactly what the
+    lane-per-pair kernels give for the matrix scorer (8 192 pairs of 10 kb, no oracle involved)."""
+    import torch
+    from blasr_amd import api, _lib
+    n = 8192
+    host = synth.compact_blocks(synth.preset("c2_10kb_linear", n)[0])
+    kw = dict(match=-5, mismatch=6, ins=5, dele=4, band=10)
+    sc = api.make_scoring(**kw)
+    code = np.full(256, 4, np.int64)
+    for i, c in enumerate(b"ACGT"):
+        code[c] = i; code[c + 32] = i
+    sub = np.array([[sc.sub[a][b] for b in range(5)] for a in range(5)], np.int16)
+    qc = code[host["q_arena"]]
+    prof = np.zeros((len(qc), 11), np.int16)
+    prof[:, :5] = sub[qc]
+    prof[:, 5] = kw["ins"]
+    prof[:, 6:] = kw["dele"]
+    monkeypatch.setenv("GBA_WAVE_PAIRS", "1000")          # the plain run one lane per pair even at this batch size
+    ctx = api.Context(0, timing=True)
+    ctx.set_scoring(sc)
+    d = api.to_device(host)
+    cap = int(host["q_len"].astype(np.int64).sum() // 4) + n
+    outs = []
+    for b in (d, dict(d, q_profile=torch.from_numpy(prof.reshape(-1)).to("cuda:0"))):
+        op = torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0")
+        ob = torch.zeros((cap, 3), dtype=torch.int32, device="cuda:0")
+        rc, needed = ctx.refine_device(b, op, ob)
+        torch.cuda.synchronize()
+        assert rc == 0
+        outs.append((op.cpu().numpy().tobytes(), ob[:needed].cpu().numpy().tobytes(), int(ctx.timing()["wide_pairs"])))
+    assert outs[0][:2] == outs[1][:2]
+    assert outs[0][2] < n // 2 and outs[1][2] == n           # lane-per-pair kernels against wave-per-pair kernels
+    ctx.close()
