@@ -133,6 +133,12 @@ def test_extension_forwards_and_backwards(api, oracle):
         P = api.make_kband_params(align_type=_lib.KB_EXTEND, ins=5, dele=4, max_drops=drops)
         got = _run_and_compare(api, oracle, ctx, pairs, ks, P, reverse=np.array(reverse, np.uint8))
     assert (got["dp_score"] <= 0).all()
+    # other bands: up to 16 the extensions run one lane per pair (two register-window sizes), beyond that one wave per pair;
+    # mixed bands in one batch; both tie-breaks
+    P = api.make_kband_params(align_type=_lib.KB_EXTEND, ins=5, dele=4, max_drops=5, tie_break=1)
+    for kk in (0, 1, 7, 11, 16, 17):
+        _run_and_compare(api, oracle, ctx, pairs, [kk] * len(pairs), P, reverse=np.array(reverse, np.uint8))
+    _run_and_compare(api, oracle, ctx, pairs, [int(x) for x in rng.integers(0, 17, len(pairs))], P, reverse=np.array(reverse, np.uint8))
     long_q = np.concatenate([pairs[0][0]] * 20)[:4200]
     r = ctx.kband_host(pack([(long_q, long_q)], [10]), P)[0]
     assert int(r[0]["status"]) == _lib.PAIR_TOO_LONG
