@@ -1064,9 +1064,40 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t 
 // Both are prefix minima of a(j) - j * slope for the two slopes P and E: two wave scans with scalar
 // carries between chunks.  The words of the left neighbour are then rebuilt from x and y, and the
 // arrow, the gap bits and the tie-breaks are decided per cell exactly as in k_fill<true>.
-template <bool NARROW>
+//
+// QV (AffineGuidedAlign(..., idsScoreFn, ...), /root/reference/iblasr/BlasrUtilsImpl.hpp:707-710): substitution, insertion and
+// the one-base deletion take their costs from the profile (within +-63 here: the affine cell word has one score bit fewer),
+// gap open and extend stay constants.  The deletion cost now differs from column to column, so the two slopes no longer
+// describe the row: the pair (M score, D score) of a column is a min-plus affine map of the pair of the column to its left,
+//     x(k) = min( a(k), x(k-1) + min(del(k), OE), y(k-1) + E ),   y(k) = min( x(k-1) + OE, y(k-1) + E ),
+// and the wave scan composes these maps (a 2 x 2 min-plus matrix and a 2-vector per lane) instead of taking two prefix minima.
+struct RowMap { int32_t m00, m01, m10, m11, b0, b1; };      // x' = min(m00 + x, m01 + y, b0), y' = min(m10 + x, m11 + y, b1)
+
+template <int CTRL, int ROWS>
+__device__ __forceinline__ void rowmap_step(RowMap &g, int32_t big)
+{
+    // f: the map accumulated by the lanes below (applied first); lanes the pattern does not reach see the identity map
+    RowMap f;
+    f.m00 = __builtin_amdgcn_update_dpp(0, g.m00, CTRL, ROWS, 0xf, false);
+    f.m01 = __builtin_amdgcn_update_dpp(big, g.m01, CTRL, ROWS, 0xf, false);
+    f.m10 = __builtin_amdgcn_update_dpp(big, g.m10, CTRL, ROWS, 0xf, false);
+    f.m11 = __builtin_amdgcn_update_dpp(0, g.m11, CTRL, ROWS, 0xf, false);
+    f.b0 = __builtin_amdgcn_update_dpp(big, g.b0, CTRL, ROWS, 0xf, false);
+    f.b1 = __builtin_amdgcn_update_dpp(big, g.b1, CTRL, ROWS, 0xf, false);
+    RowMap h;
+    h.m00 = min(g.m00 + f.m00, g.m01 + f.m10); h.m01 = min(g.m00 + f.m01, g.m01 + f.m11);
+    h.m10 = min(g.m10 + f.m00, g.m11 + f.m10); h.m11 = min(g.m10 + f.m01, g.m11 + f.m11);
+    h.b0 = min(min(g.m00 + f.b0, g.m01 + f.b1), g.b0);
+    h.b1 = min(min(g.m10 + f.b0, g.m11 + f.b1), g.b1);
+    // entries stay below 2^31: no entry of a composed map exceeds `big` plus the row's largest path cost
+    h.m01 = min(h.m01, big); h.m10 = min(h.m10, big); h.b0 = min(h.b0, big + big / 4); h.b1 = min(h.b1, big + big / 4);
+    g = h;
+}
+
+template <bool NARROW, bool QV = false>
 __global__ __launch_bounds__(64) void k_fill_wide_affine(Dev d, FillConst fc, uint32_t cls)
 {
+    __shared__ int32_t ptab[16];
     constexpr int WIDE_SBUF = NARROW ? WN_SBUF : ::WIDE_SBUF;
     __shared__ uint32_t ringM[NARROW ? WN_RING : WIDE_RING];
     __shared__ uint32_t ringI[NARROW ? WN_RING : WIDE_RING];
@@ -1088,8 +1119,14 @@ __global__ __launch_bounds__(64) void k_fill_wide_affine(Dev d, FillConst fc, ui
     const bool y_by_e = E <= P;                         // slope of the cheapest way to lengthen a path that ends in the gap state
     uint32_t spos = 0, sload = 0;
     uint32_t W = 0, Wp = 0, dsh = 0, roff = 0;
+    const int16_t *prow = QV ? d.prof + (d.q_off[p] + d.qS[p]) * 11 : nullptr;      // row r >= 1 uses prow[(r - 1) * 11 ..]
+    int32_t pnext = QV && Q >= 1u && lane < 11 ? (int32_t)prow[lane] : 0;
     __syncthreads();
     for (uint32_t r = 0; r <= Q; r++) {
+        if constexpr (QV) {
+            if (lane < 11) ptab[lane] = min(max(pnext, -63), 63);                // read after the barriers below
+            if (r + 1u <= Q && r >= 1u && lane < 11) pnext = (int32_t)prow[(size_t)r * 11 + lane];
+        }
         while (sload - spos < (uint32_t)WIDE_SBUF / 2 && sload < wcap) {
             const uint32_t x = sload + lane;
             const uint32_t v = x < wcap ? st[x] : 0u;
@@ -1128,28 +1165,48 @@ __global__ __launch_bounds__(64) void k_fill_wide_affine(Dev d, FillConst fc, ui
             const uint32_t diag = (uint32_t)__builtin_amdgcn_update_dpp((int32_t)cdiag, (int32_t)up, 0x138, 0xf, 0xf, false);
             cdiag = (uint32_t)__builtin_amdgcn_readlane((int32_t)up, 63);
             const uint32_t tcd = up & 7u;
-            const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);
+            uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);
+            int32_t cU = fc.cU, cL = fc.cL;
+            if constexpr (QV) {
+                if (r != 0u) {                                         // row 0 (no query base) keeps the matrix and the fixed deletion
+                    const uint32_t ti = min(max(tcd, 1u), 5u) - 1u;
+                    sb = (uint32_t)(ptab[ti] + 128);
+                    cU += (ptab[5] - fc.ins) * 64;
+                    cL += (ptab[6 + ti] - fc.del) * 64;
+                }
+            }
             const int32_t m = (int32_t)((sb << 6) + diag);
-            const int32_t u = (int32_t)up + fc.cU;
+            const int32_t u = (int32_t)up + cU;
             const int32_t io = (int32_t)(up & ~TAGS) + fc.cIO, ie = (int32_t)upi + fc.cIE;
             const uint32_t ig = (uint32_t)min(io, ie);                 // bit 2: 1 = extend
             const int32_t ic = (int32_t)ig + (4 << 3);
             const int32_t av = min(m, min(u, ic));                     // best of the moves that do not come from the left
             const int32_t a = (int32_t)((uint32_t)av & ~TAGS);
-            const int32_t inc1 = wave_scan_min(a - lane * P, BIG), inc2 = wave_scan_min(a - lane * E, BIG);
-            const int32_t ex1 = __builtin_amdgcn_update_dpp(BIG, inc1, 0x138, 0xf, 0xf, false);
-            const int32_t ex2 = __builtin_amdgcn_update_dpp(BIG, inc2, 0x138, 0xf, 0xf, false);
-            const int32_t s1 = min(ex1, carry1) + lane * P;            // best a(j) + (k - j) * P over j < k
-            const int32_t s2 = min(ex2, carry2) + lane * E;            // best a(j) + (k - j) * E over j < k
-            carry1 = min(__builtin_amdgcn_readlane(inc1, 63), carry1) + 64 * P;
-            carry2 = min(__builtin_amdgcn_readlane(inc2, 63), carry2) + 64 * E;
-            const int32_t x = min(a, min(s1, s2 + OE - E));            // score of M[k]
-            const int32_t y = y_by_e ? s2 + OE - E : s1 + OE - P;      // score of D[k]
+            int32_t x, y;
+            if constexpr (QV) {
+                RowMap g;
+                g.m00 = min((int32_t)((uint32_t)cL & ~TAGS), OE); g.m01 = E; g.m10 = OE; g.m11 = E; g.b0 = a; g.b1 = BIG;
+                rowmap_step<0x111, 0xf>(g, BIG); rowmap_step<0x112, 0xf>(g, BIG); rowmap_step<0x114, 0xf>(g, BIG);
+                rowmap_step<0x118, 0xf>(g, BIG); rowmap_step<0x142, 0xa>(g, BIG); rowmap_step<0x143, 0xc>(g, BIG);
+                const int32_t xin = min((int32_t)xl, BIG), yin = min((int32_t)yl, BIG);       // scores may be negative: signed
+                x = min(min(g.m00 + xin, g.m01 + yin), g.b0);          // score of M[k]: the chunk's maps applied to the column left of it
+                y = min(min(g.m10 + xin, g.m11 + yin), g.b1);          // score of D[k]
+            } else {
+                const int32_t inc1 = wave_scan_min(a - lane * P, BIG), inc2 = wave_scan_min(a - lane * E, BIG);
+                const int32_t ex1 = __builtin_amdgcn_update_dpp(BIG, inc1, 0x138, 0xf, 0xf, false);
+                const int32_t ex2 = __builtin_amdgcn_update_dpp(BIG, inc2, 0x138, 0xf, 0xf, false);
+                const int32_t s1 = min(ex1, carry1) + lane * P;            // best a(j) + (k - j) * P over j < k
+                const int32_t s2 = min(ex2, carry2) + lane * E;            // best a(j) + (k - j) * E over j < k
+                carry1 = min(__builtin_amdgcn_readlane(inc1, 63), carry1) + 64 * P;
+                carry2 = min(__builtin_amdgcn_readlane(inc2, 63), carry2) + 64 * E;
+                x = min(a, min(s1, s2 + OE - E));                          // score of M[k]
+                y = y_by_e ? s2 + OE - E : s1 + OE - P;                    // score of D[k]
+            }
             // the words of the left neighbour, then the cell exactly as the lane-per-pair kernel computes it
             const uint32_t xp = (uint32_t)__builtin_amdgcn_update_dpp((int32_t)xl, x, 0x138, 0xf, 0xf, false);
             const uint32_t yp = (uint32_t)__builtin_amdgcn_update_dpp((int32_t)yl, y, 0x138, 0xf, 0xf, false);
             xl = (uint32_t)__builtin_amdgcn_readlane(x, 63); yl = (uint32_t)__builtin_amdgcn_readlane(y, 63);
-            const int32_t l = (int32_t)xp + fc.cL;
+            const int32_t l = (int32_t)xp + cL;
             const int32_t dop = (int32_t)xp + fc.cDO, de = (int32_t)yp + fc.cDE;
             const uint32_t dg = (uint32_t)min(dop, de);                // bit 1: 1 = extend
             const int32_t dc = (int32_t)dg + (3 << 3);
@@ -2390,11 +2447,13 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
         }
         if (wave) {
             if (k == CLS_WIDE) {
-                if (aff) hipLaunchKernelGGL(k_fill_wide_affine<false>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+                if (aff && d.prof) hipLaunchKernelGGL((k_fill_wide_affine<false, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+                else if (aff) hipLaunchKernelGGL((k_fill_wide_affine<false>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else if (d.prof) hipLaunchKernelGGL((k_fill_wide<4, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else hipLaunchKernelGGL(k_fill_wide<4>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
             } else {
-                if (aff) hipLaunchKernelGGL(k_fill_wide_affine<true>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+                if (aff && d.prof) hipLaunchKernelGGL((k_fill_wide_affine<true, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+                else if (aff) hipLaunchKernelGGL((k_fill_wide_affine<true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else if (d.prof) hipLaunchKernelGGL((k_fill_wide<1, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else hipLaunchKernelGGL(k_fill_wide<1>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
             }
@@ -2623,7 +2682,6 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
     g.q_len = b->q_len; g.t_len = b->t_len; g.n_blk = b->n_blk;
     g.guide_status = c->cur_guide_status;
     g.prof = b->q_profile;
-    if (g.prof && c->sc.mode == GBA_MODE_AFFINE) return GBA_E_UNSUPPORTED;
     g.status = (int32_t *)c->b_pair32[0].ptr;
     g.qS = (uint32_t *)c->b_pair32[1].ptr; g.tS = (uint32_t *)c->b_pair32[2].ptr;
     g.Q = (uint32_t *)c->b_pair32[3].ptr; g.T = (uint32_t *)c->b_pair32[4].ptr;
@@ -3144,7 +3202,6 @@ static int run_host_batch(gba_ctx *c, const gba_batch *b, gba_results *out)
     db.blocks = (const gba_block *)c->s_blk.ptr;
     if (b->q_profile) {
         // the profile goes first on the stream of the input copies: every part's "inputs have arrived" event follows it
-        if (c->sc.mode == GBA_MODE_AFFINE) return GBA_E_UNSUPPORTED;
         HIPCHK(c, hipMemcpyAsync(c->s_prof.ptr, b->q_profile, (size_t)b->q_arena_bytes * 22, hipMemcpyHostToDevice, c->s_in));
         db.q_profile = (const int16_t *)c->s_prof.ptr;
     }

@@ -70,14 +70,16 @@ inline void MatrixFromParams(const MappingParameters &p, gba_scoring &s)
         for (int b = 0; b < 5; b++) s.sub[a][b] = (a == 4 || b == 4) ? 0 : (a == b ? p.match : p.mismatch);
 }
 
-inline gba_scoring ScoringFromParams(const MappingParameters &p)
+// ids: the DP runs with idsScoreFn (a batch that brings cost profiles), the one scorer that receives
+// params.affineOpen / affineExtend (:643-644)
+inline gba_scoring ScoringFromParams(const MappingParameters &p, bool ids = false)
 {
     gba_scoring s{};
     MatrixFromParams(p, s);
     // distScoreFn(SMRTDistanceMatrix, params.deletion, params.insertion), read as ctor(ins, del): :630-631
     s.ins = p.deletion; s.del = p.insertion;
     s.stats_ins = s.stats_del = p.indel;                       // distScoreFn2, :633-634
-    s.affine_open = kDistScorerAffineOpen; s.affine_extend = kDistScorerAffineExtend;
+    s.affine_open = ids ? p.affineOpen : kDistScorerAffineOpen; s.affine_extend = ids ? p.affineExtend : kDistScorerAffineExtend;
     s.stats_affine_open = kStatsScorerAffineOpen; s.stats_affine_extend = kStatsScorerAffineExtend;
     s.band = p.affineAlign ? p.bandSize : p.guidedAlignBandSize;   // :706-731
     s.max_band = p.maxBandSize;
@@ -232,7 +234,7 @@ public:
     {
         const uint32_t n = (uint32_t)cands_.size();
         if (n == 0) return GBA_OK;
-        gba_scoring sc = ScoringFromParams(params);
+        gba_scoring sc = ScoringFromParams(params, !prof_.empty());
         int rc = gba_set_scoring(ctx_, &sc);
         if (rc != GBA_OK) return rc;
         if (t_arena_.empty()) t_arena_.push_back('N');

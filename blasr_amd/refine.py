@@ -92,17 +92,20 @@ STATS_SCORER_AFFINE_OPEN = 0       # distScoreFn2.affineOpen  (ComputeAlignmentS
 STATS_SCORER_AFFINE_EXTEND = 0     # distScoreFn2.affineExtend
 
 
-def scoring_from_params(p: MappingParameters):
+def scoring_from_params(p: MappingParameters, ids: bool = False):
     """distScoreFn(SMRTDistanceMatrix, params.deletion, params.insertion) read as ctor(ins, del)
     (:630-631) and distScoreFn2(indel, indel) (:633-634); band per :706-731.  The affine costs of
-    both scorers are the constructor defaults above, NOT params.affineOpen / affineExtend."""
+    both scorers are the constructor defaults above, NOT params.affineOpen / affineExtend.
+    ids: the DP runs with idsScoreFn, the one scorer that does receive params.affineOpen / affineExtend
+    (:643-644); its per-base costs travel beside this as a profile."""
     if p.doGlobalAlignment:
         raise ValueError("the -global branch has its own scorer and band: use scoring_global() / refine_global()")
     mode = _lib.MODE_AFFINE if p.affineAlign else _lib.MODE_LINEAR
     band = p.bandSize if p.affineAlign else p.guidedAlignBandSize
     return make_scoring(match=p.match, mismatch=p.mismatch, ins=p.deletion, dele=p.insertion,
                         indel=p.indel, band=band, max_band=p.maxBandSize, mode=mode,
-                        tie_break=p.tieBreak, affine_open=DIST_SCORER_AFFINE_OPEN, affine_extend=DIST_SCORER_AFFINE_EXTEND,
+                        tie_break=p.tieBreak, affine_open=p.affineOpen if ids else DIST_SCORER_AFFINE_OPEN,
+                        affine_extend=p.affineExtend if ids else DIST_SCORER_AFFINE_EXTEND,
                         stats_affine=1 if p.affineAlign else 0, stats_affine_open=STATS_SCORER_AFFINE_OPEN,
                         stats_affine_extend=STATS_SCORER_AFFINE_EXTEND, sub=p.scoreMatrix)
 
@@ -325,8 +328,8 @@ def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: Mappi
     prints only what the pair results hold: no block leaves the device.
     qv: the read's QualityValues.  With params.ignoreQualities off and meaningful quality values the guided DP runs with
     the IDS scorer (GuidedAlign(qSeq, tSeq, alignmentCandidate, idsScoreFn, params.guidedAlignBandSize, ...), :705-717):
-    its costs travel as gba_batch.q_profile (ids_profile).  AffineGuidedAlign with the IDS scorer (:707-710) is not on the
-    device: NotImplementedError."""
+    its costs travel as gba_batch.q_profile (ids_profile).  With params.affineAlign that is AffineGuidedAlign with the IDS
+    scorer (:707-710): per-base substitution / insertion / deletion costs (within +-63) and params.affineOpen / affineExtend."""
     if not params.refineAlignments or not cands:
         return cands
     use_qv = qv is not None and not params.ignoreQualities and ReadHasMeaningfulQualityValues(qv)
@@ -343,9 +346,7 @@ def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: Mappi
         if params.sortRefinedAlignments:
             cands.sort(key=lambda c: c.score)
         return cands
-    if use_qv and params.affineAlign:
-        raise NotImplementedError("AffineGuidedAlign with the IDS scorer (:707-710) is not on the accelerated path")
-    ctx.set_scoring(scoring_from_params(params))
+    ctx.set_scoring(scoring_from_params(params, ids=use_qv))
     batch = build_batch(read, cands)
     if use_qv:
         batch["q_profile"] = ids_profile(read, qv, params)

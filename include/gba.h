@@ -139,11 +139,12 @@ typedef struct {
                                    of the bytes cross the link; the device spells the letters out again as each part arrives. */
     const int16_t *q_profile;   /* NULL, or the costs of a quality-value scorer in place of matrix, ins and del for the DP of this
                                    batch: GuidedAlign(qSeq, tSeq, alignmentCandidate, idsScoreFn, band, ...) of
-                                   iblasr/BlasrUtilsImpl.hpp:705-717 (linear gaps; GBA_E_UNSUPPORTED with GBA_MODE_AFFINE).
+                                   iblasr/BlasrUtilsImpl.hpp:705-717, and with GBA_MODE_AFFINE the AffineGuidedAlign call of :707-710.
                                    11 values per base of q_arena (per BASE when the reads are packed), for the base at arena
                                    position x: q_profile[11 x + c] = Match against target code c (A, C, G, T, N),
                                    q_profile[11 x + 5] = Insertion of the base, q_profile[11 x + 6 + c] = Deletion of a
-                                   target base of code c behind it; each taken within +-127.  Deletions in front of the first
+                                   target base of code c behind it; each taken within +-127 (+-63 with GBA_MODE_AFFINE, whose gap
+                                   open and extend stay gba_scoring's constants).  Deletions in front of the first
                                    query base cost gba_scoring.del.  The rescoring (stats_*, extra[]) is unchanged.  Host
                                    pointer for gba_submit (copied whole before the first part), device pointer for
                                    gba_submit_device / _noalloc.  Such batches run on the wave-per-pair kernels. */

@@ -254,12 +254,13 @@ static int add_inf(int s, int c) { return s >= GBO_INF ? GBO_INF : s + c; }
  * and statistics for one pair.  q/t are ASCII; blocks index into them.
  * blocks_out receives up to blk_cap blocks relative to (res->q_pos, res->t_pos).
  */
-static int clamp127(int v) { return v < -127 ? -127 : v > 127 ? 127 : v; }
+static int clamp_to(int v, int lim) { return v < -lim ? -lim : v > lim ? lim : v; }
 
 /* prof (may be NULL): the costs of a quality-value scorer (IDSScoreFunction: GuidedAlign(..., idsScoreFn, ...),
  * /root/reference/iblasr/BlasrUtilsImpl.hpp:705-717) as 11 int16 per query base, indexed like q: Match against
  * target code A, C, G, T, N; Insertion of the base; Deletion of a target base of code A, C, G, T, N behind it.
- * Values are taken within +-127; row 0 (before the first query base) deletes at P->del.  Linear gaps only. */
+ * Values are taken within +-127 (+-63 in the affine model, AffineGuidedAlign(..., idsScoreFn, ...), :707-710, where gap
+ * open and extend stay P's constants); row 0 (before the first query base) deletes at P->del. */
 int gbo_align_qv(const uint8_t *q, uint32_t q_len, const uint8_t *t, uint32_t t_len,
                  const gbo_block *b, int nb, const gbo_params *P, const int16_t *prof,
                  gbo_block *blocks_out, uint32_t blk_cap, gbo_result *res)
@@ -315,9 +316,10 @@ int gbo_align_qv(const uint8_t *q, uint32_t q_len, const uint8_t *t, uint32_t t_
             if (tt - 1 < tStart - 1) li = -1;
             int m = GBO_INF, u = GBO_INF, l = GBO_INF;
             const int16_t *pr = (prof && r > 0) ? prof + (size_t)qi * 11 : NULL;
-            if (mi >= 0) m = add_inf(S[mi], pr ? clamp127(pr[gbo_code(t[tt])]) : P->sub[gbo_code(q[qi])][gbo_code(t[tt])]);
-            if (ui >= 0) u = add_inf(S[ui], pr ? clamp127(pr[5]) : P->ins);
-            if (li >= 0) l = add_inf(S[li], pr ? clamp127(pr[6 + gbo_code(t[tt])]) : P->del);
+            const int lim = affine ? 63 : 127;
+            if (mi >= 0) m = add_inf(S[mi], pr ? clamp_to(pr[gbo_code(t[tt])], lim) : P->sub[gbo_code(q[qi])][gbo_code(t[tt])]);
+            if (ui >= 0) u = add_inf(S[ui], pr ? clamp_to(pr[5], lim) : P->ins);
+            if (li >= 0) l = add_inf(S[li], pr ? clamp_to(pr[6 + gbo_code(t[tt])], lim) : P->del);
             int best; uint8_t arrow;
             pick3(m, l, u, P->tie_break, &best, &arrow);
             if (affine) {

@@ -199,7 +199,7 @@ def check_kband(rng, api, oracle, _lib, ctx, pool, batch):
 
 def check_qv(rng, api, oracle, _lib, ctx, pool, batch, kw):
     """The round's batch again with the costs of a quality-value scorer (gba_batch.q_profile, random values, some outside
-    +-127) against gbo_align_qv.  Linear gaps and the k-band geometry only."""
+    +-127, or +-63 with affine gaps) against gbo_align_qv: linear and affine gaps, the k-band geometry."""
     n = int(batch["n_pairs"])
     na = len(batch["q_arena"])
     prof = rng.integers(-20, 60, (na, 11)).astype(np.int16)
@@ -322,7 +322,7 @@ def main():
             sdp_rounds += 1
             if bad:
                 kw = dict(kw, sdp=skw)
-        if not bad and rounds % 4 == 3 and kw["mode"] != _lib.MODE_AFFINE:
+        if not bad and rounds % 4 == 3:
             bad = check_qv(rng, api, oracle, _lib, ctx, pool, batch, kw)
             qv_rounds += 1
         if not bad and rounds % 3 == 1:

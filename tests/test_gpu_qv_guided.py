@@ -76,7 +76,7 @@ def test_profile_costs_in_the_guided_dp(oracle, synth, band, tie):
     ctx.close()
 
 
-def test_profile_with_the_kband_geometry_and_refusal_with_affine_gaps(oracle, synth):
+def test_profile_with_the_kband_geometry(oracle, synth):
     from blasr_amd import api, _lib
     rng = np.random.default_rng(2)
     batch = synth.compact_blocks(synth.generate(40, read_len=500, len_jitter=100, seed=9))
@@ -87,22 +87,75 @@ def test_profile_with_the_kband_geometry_and_refusal_with_affine_gaps(oracle, sy
     pairs, blocks, rc = ctx.refine_host(dict(batch, q_profile=prof))
     assert rc == 0
     _check(oracle, batch, prof, oracle.make_params(**kw), pairs, blocks)
-    ctx.set_scoring(api.make_scoring(mode=_lib.MODE_AFFINE, band=16))
-    ctx.submit_host(dict(batch, q_profile=prof), np.zeros(40, _lib.PAIR_RESULT_DT), np.zeros(40 * 600, _lib.BLOCK_DT))
-    with pytest.raises(api.GbaError) as e:
-        ctx.wait_host()
-    assert e.value.code == _lib.E_UNSUPPORTED
     ctx.close()
 
 
-def test_refine_alignments_with_quality_values(oracle, synth):
+@pytest.mark.parametrize("band,oe", [(8, (4, 1)), (16, (10, 0)), (150, (3, 2)), (40, (0, 7))])
+def test_profile_costs_with_affine_gaps(oracle, synth, band, oe):
+    """AffineGuidedAlign with the IDS scorer (/root/reference/iblasr/BlasrUtilsImpl.hpp:707-710): per-base costs for
+    substitution, insertion and the one-base deletion (taken within +-63), constant gap open / extend; narrow and wide
+    rows, both tie-breaks, an extend cost above and below the per-base deletion costs, host and device batches."""
+    import torch
+    from blasr_amd import api, _lib
+    rng = np.random.default_rng(17 + band)
+    batch = synth.compact_blocks(synth.generate(96, read_len=800, len_jitter=500, seed=3 + band))
+    prof = _profile(rng, batch)
+    ctx = api.Context(0)
+    for tie in (0, 1):
+        kw = dict(mode=_lib.MODE_AFFINE, band=band, tie_break=tie, ins=5, dele=4, affine_open=oe[0], affine_extend=oe[1],
+                  stats_affine=1, stats_affine_open=2, stats_affine_extend=1)
+        ctx.set_scoring(api.make_scoring(**kw))
+        with_prof = dict(batch, q_profile=prof)
+        pairs, blocks, rc = ctx.refine_host(with_prof)
+        assert rc == 0 and int((pairs["status"] == 0).sum()) == 96
+        _check(oracle, batch, prof, oracle.make_params(**kw), pairs, blocks)
+    plain, _, _ = ctx.refine_host(batch)
+    assert (plain["dp_score"] != pairs["dp_score"]).any()
+    d = api.to_device(with_prof)
+    out_pairs = torch.zeros(96 * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0")
+    out_blocks = torch.zeros((len(blocks) + 8, 3), dtype=torch.int32, device="cuda:0")
+    rc, needed = ctx.refine_device(d, out_pairs, out_blocks)
+    torch.cuda.synchronize()
+    assert rc == 0 and out_pairs.cpu().numpy().view(_lib.PAIR_RESULT_DT).tobytes() == pairs.tobytes()
+    ctx.close()
+
+
+def test_affine_profile_that_spells_out_the_matrix_gives_the_plain_affine_results(synth):
+    """A profile whose costs are the matrix row of each base, ins and del: the composed-map row scan of the
+    quality-value kernel reproduces the two-slope scan of the plain affine kernel (no oracle involved), reads of 6 kb."""
+    from blasr_amd import api, _lib
+    n = 256
+    host = synth.compact_blocks(synth.generate(n, read_len=6000, len_jitter=1000, seed=77))
+    kw = dict(mode=_lib.MODE_AFFINE, match=-5, mismatch=6, ins=5, dele=4, band=16, affine_open=6, affine_extend=2, stats_affine=1)
+    sc = api.make_scoring(**kw)
+    code = np.full(256, 4, np.int64)
+    for i, c in enumerate(b"ACGT"):
+        code[c] = i; code[c + 32] = i
+    sub = np.array([[sc.sub[a][b] for b in range(5)] for a in range(5)], np.int16)
+    qc = code[host["q_arena"]]
+    prof = np.zeros((len(qc), 11), np.int16)
+    prof[:, :5] = sub[qc]
+    prof[:, 5] = kw["ins"]
+    prof[:, 6:] = kw["dele"]
+    ctx = api.Context(0)
+    ctx.set_scoring(sc)
+    a = ctx.refine_host(host)
+    b = ctx.refine_host(dict(host, q_profile=prof.reshape(-1)))
+    assert a[2] == 0 and b[2] == 0 and int((a[0]["status"] == 0).sum()) == n
+    assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+    ctx.close()
+
+
+@pytest.mark.parametrize("affine", [False, True])
+def test_refine_alignments_with_quality_values(oracle, synth, affine):
     """refine.RefineAlignments(..., qv=...) with -useQuality: the IDS scorer's costs (refine.ids_profile) drive the
-    guided DP; against the oracle on the same slices and costs."""
+    guided DP (with -affineAlign: AffineGuidedAlign, gap costs params.affineOpen / affineExtend); against the oracle on
+    the same slices and costs."""
     from blasr_amd import api, refine
     rng = np.random.default_rng(11)
     batch = synth.generate(6, read_len=700, len_jitter=200, seed=123)
     ctx = api.Context(0)
-    params = refine.MappingParameters(ignoreQualities=False)
+    params = refine.MappingParameters(ignoreQualities=False, affineAlign=affine)
     ACGT = np.frombuffer(b"ACGT", np.uint8)
     for i in range(6):
         q, t, blk = synth.pair(batch, i)
@@ -117,6 +170,11 @@ def test_refine_alignments_with_quality_values(oracle, synth):
         ql = int(rel[-1]["q_pos"]) + int(rel[-1]["length"]); tl = int(rel[-1]["t_pos"]) + int(rel[-1]["length"])
         prof = refine.ids_profile(read, qv, params)
         OP = oracle.make_params(ins=params.deletion, dele=params.insertion, indel=params.indel, band=params.guidedAlignBandSize)
+        if affine:
+            OP = oracle.make_params(ins=params.deletion, dele=params.insertion, indel=params.indel, band=params.bandSize,
+                                    mode=oracle.MODE_AFFINE, affine_open=params.affineOpen, affine_extend=params.affineExtend,
+                                    stats_affine=1, stats_affine_open=refine.STATS_SCORER_AFFINE_OPEN,
+                                    stats_affine_extend=refine.STATS_SCORER_AFFINE_EXTEND)
         want, wb = oracle.align_qv(read[q0:q0 + ql], bytes(t)[t0:t0 + tl], rel, OP, prof[q0 * 11:(q0 + ql) * 11])
         assert c.status == 0 and want["status"] == 0
         assert (c.score, c.nCells, c.nMatch, len(c.blocks)) == (want["score"], want["ncells"], want["n_match"], want["n_blk"])

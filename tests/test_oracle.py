@@ -138,3 +138,38 @@ def test_affine_model(oracle):
     P2 = oracle.make_params(mode=oracle.MODE_AFFINE, ins=100, dele=100, affine_open=10, affine_extend=0, band=16)
     r2, _ = oracle.align(q, t, [(0, 0, 12), (15, 12, 12)], P2)
     assert r2["dp_score"] == -120 + 10
+
+
+def test_quality_value_costs_in_both_gap_models(oracle, synth):
+    """gbo_align_qv: a profile that spells out the matrix row of every base, ins and del gives the plain results, linear and
+    affine; a hand-checked case where one base's quality makes its deletion cheap; profile values are taken within
+    +-127 (linear) and +-63 (affine)."""
+    batch = synth.generate(6, read_len=300, seed=5, threads=1)
+    for mode, extra in ((oracle.MODE_LINEAR, {}), (oracle.MODE_AFFINE, dict(affine_open=6, affine_extend=2))):
+        kw = dict(mode=mode, ins=5, dele=4, band=12, **extra)
+        P = oracle.make_params(**kw)
+        for i in range(6):
+            q, t, blk = synth.pair(batch, i)
+            code = {65: 0, 67: 1, 71: 2, 84: 3}
+            prof = np.zeros((len(q), 11), np.int16)
+            for x, c in enumerate(q):
+                prof[x, :5] = [P.sub[code.get(int(c) & 0xdf, 4)][b] for b in range(5)]
+            prof[:, 5] = 5
+            prof[:, 6:] = 4
+            a, ab = oracle.align(q, t, blk, P)
+            b, bb = oracle.align_qv(q, t, blk, P, prof.reshape(-1))
+            assert a == b and (ab == bb).all()
+        # q = ACGT ACGT, t = ACGT G ACGT: the extra G is deleted behind query base 3; its cost comes from that base's entry
+        q, t = b"ACGTACGT", b"ACGTGACGT"
+        prof = np.zeros((8, 11), np.int16)
+        prof[:, :5] = 6
+        for x, c in enumerate(q):
+            prof[x, b"ACGT".index(c)] = -5
+        prof[:, 5] = 9
+        prof[:, 6:] = 9
+        prof[3, 6 + 2] = 1                                  # deleting a G behind query base 3
+        r, blocks = oracle.align_qv(q, t, [(0, 0, 4), (4, 5, 4)], oracle.make_params(**dict(kw, affine_open=20)), prof.reshape(-1))
+        assert r["status"] == 0 and r["dp_score"] == -40 + 1 and r["n_del"] == 1
+        prof[:, 5:] = 500                                   # every gap move dearer than the limit: exactly one deletion is needed
+        r, _ = oracle.align_qv(q, t, [(0, 0, 4), (4, 5, 4)], oracle.make_params(**dict(kw, affine_open=200, dele=120)), prof.reshape(-1))   # row 0 deletes at dele
+        assert r["dp_score"] == -40 + (63 if mode == oracle.MODE_AFFINE else 127)

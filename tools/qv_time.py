@@ -1,4 +1,4 @@
-"""The guided DP with and without a quality-value profile (gba_batch.q_profile), device-resident, 32 768 pairs of 10 kb."""
+"""The guided DP with and without a quality-value profile (gba_batch.q_profile), linear and affine gaps, device-resident, 32 768 pairs of 10 kb."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +19,10 @@ ctx = api.Context(0, timing=True)
 ctx.set_scoring(api.make_scoring())
 out_pairs = torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0")
 out_blocks = torch.zeros((int(host["q_len"].astype(np.int64).sum() // 4) + n, 3), dtype=torch.int32, device="cuda:0")
-for name, b in (("matrix scorer (wave-per-pair kernels forced: GBA_WAVE_PAIRS)", host), ("quality-value profile", dict(host, q_profile=prof.reshape(-1)))):
+aff = dict(mode=_lib.MODE_AFFINE, band=16, affine_open=6, affine_extend=2, stats_affine=1)
+for name, b, kw in (("matrix scorer (wave-per-pair kernels forced: GBA_WAVE_PAIRS)", host, {}), ("quality-value profile", dict(host, q_profile=prof.reshape(-1)), {}),
+                    ("affine gaps, matrix scorer (wave-per-pair kernels forced)", host, aff), ("affine gaps, quality-value profile", dict(host, q_profile=prof.reshape(-1)), aff)):
+    ctx.set_scoring(api.make_scoring(**kw))
     d = api.to_device(b)
     ctx.refine_device(d, out_pairs, out_blocks)
     torch.cuda.synchronize()
