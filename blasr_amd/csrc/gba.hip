@@ -1231,6 +1231,191 @@ __global__ __launch_bounds__(64) void k_fill_wide_affine(Dev d, FillConst fc, ui
     }
 }
 
+// ---------------------------------------------------------------- k_fill_quad_affine
+// The narrow affine instance again with FOUR pairs per wave: rows of the narrow class are 33 to 64 cells wide, so a
+// wave with one lane per column idles on up to half its lanes and pays the whole per-row bookkeeping for one pair.
+// Here a pair has 16 lanes (one DPP row) and a lane four neighbouring columns: the 64 columns of a chunk as before,
+// a quarter of the wave-instructions per pair and row for everything but the cell code, four-step scans that never
+// leave the DPP row, and one record dword (four arrow bytes) per lane without any gather.  Recurrence, words,
+// tie-breaks and records are exactly those of k_fill_wide_affine<true>; what was wave-uniform there (row word,
+// widths, stream position) is uniform per 16 lanes here.  The four pairs of a wave run their rows in step; a pair that
+// has fewer rows idles at the end (pairs of a class are neighbours in length).
+template <int CTRL>
+__device__ __forceinline__ int32_t row16_from(int32_t identity, int32_t v)
+{
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ int32_t row16_scan_min(int32_t v, int32_t identity)
+{
+    v = min(v, row16_from<0x111>(identity, v));
+    v = min(v, row16_from<0x112>(identity, v));
+    v = min(v, row16_from<0x114>(identity, v));
+    v = min(v, row16_from<0x118>(identity, v));
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_fill_quad_affine(Dev d, FillConst fc, uint32_t cls, uint32_t count)
+{
+    constexpr int PPW = 4, CPL = 4;
+    __shared__ uint32_t ringM[PPW][WN_RING];
+    __shared__ uint32_t ringI[PPW][WN_RING];
+    __shared__ uint32_t sbuf[PPW][WN_SBUF];
+    __shared__ uint32_t tab[LDS_TAB];
+    constexpr uint32_t TAGS = 63u;
+    constexpr int32_t BIG = 0x60000000;
+    const int lane = threadIdx.x, g = lane >> 4, sub = lane & 15;
+    if (lane < 10) tab[lane] = fc.mrow[lane];
+    const uint32_t idx = blockIdx.x * PPW + (uint32_t)g;
+    const bool have = idx < count;
+    const uint32_t p = d.order[d.plan->cls_base[cls] + (have ? idx : count - 1u)];
+    const uint32_t Q = d.Q[p];
+    const uint32_t fslot = d.T[p] - d.lo_last[p];
+    const uint32_t *st = d.stream + d.word_off[p];
+    const uint32_t wcap = d.wcap[p];
+    uint32_t *rec = d.rec + d.rec_off[p];
+    uint32_t *rM = ringM[g], *rI = ringI[g], *sb_ = sbuf[g];
+    const int32_t OE = fc.cDO, E = fc.cDE - 2;          // open + extend, extend, in cell-word units
+    const int32_t DL = fc.del * 64;
+    const int32_t P = min(DL, OE);
+    const bool y_by_e = E <= P;
+    uint32_t spos = 0, sload = 0;
+    uint32_t W = 0, Wp = 0, dsh = 0, roff = 0;
+    uint32_t Qmax = have ? Q : 0u;                      // rows of the longest of the wave's pairs
+    Qmax = max(Qmax, (uint32_t)__shfl_xor((int)Qmax, 16, 64));
+    Qmax = max(Qmax, (uint32_t)__shfl_xor((int)Qmax, 32, 64));
+    Qmax = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)Qmax);
+    __syncthreads();
+    for (uint32_t r = 0; r <= Qmax; r++) {
+        const bool act = have && r <= Q;
+        // guide words: sixteen at a time per pair, at least 64 buffered (a row of this class has at most 1 + 16)
+        for (;;) {
+            const bool need = act && sload - spos < (uint32_t)WN_SBUF / 2 && sload < wcap;
+            if (!__any(need)) break;
+            if (need) {
+                const uint32_t x = sload + (uint32_t)sub;
+                sb_[x & (WN_SBUF - 1)] = x < wcap ? st[x] : 0u;
+                sload += 16;
+            }
+        }
+        __syncthreads();
+        uint32_t word = 0, nnew = 0;
+        if (act) {
+            word = sb_[spos & (WN_SBUF - 1)];
+            Wp = W;
+            W = word & ROW_W_MASK; dsh = (word >> 13) & 1023u;
+            const uint32_t tot = dsh + W;
+            nnew = tot > Wp ? tot - Wp : 0u;
+        }
+        const uint32_t qcode = (word >> 10) & 7u;
+        const uint32_t mlo = tab[qcode * 2], mhi = tab[qcode * 2 + 1];
+        // entering columns: INFW words carrying the column's base code
+        for (uint32_t x = (uint32_t)sub; __any(x < nnew); x += 16) {
+            if (x < nnew) {
+                uint32_t code;
+                if (x < 3u) code = (word >> (23u + 3u * x)) & 7u;
+                else {
+                    const uint32_t e = (x - 3u) >> 3, rr = (x - 3u) & 7u;
+                    code = (sb_[(spos + 1u + e) & (WN_SBUF - 1)] >> (3u * rr)) & 7u;
+                }
+                rM[Wp + x] = INFW | code;
+                rI[Wp + x] = INFW;
+            }
+        }
+        if (act) spos += 1u + (nnew > 3u ? (nnew + 4u) >> 3 : 0u);
+        __syncthreads();
+        // row 0: the diagonal candidate of cell (0,0) costs exactly 0
+        uint32_t cdiag = INFW;
+        if (act) cdiag = r == 0 ? (uint32_t)fc.diag0 : dsh >= 1u && dsh - 1u < Wp ? rM[dsh - 1u] : INFW;
+        int32_t carry1 = BIG, carry2 = BIG;
+        uint32_t xl = INFW, yl = INFW;
+        const uint32_t nd = (W + 3u) >> 2;
+        for (uint32_t c0 = 0; __any(act && c0 < W); c0 += 64) {
+            const bool cact = act && c0 < W;
+            const uint32_t k0 = c0 + (uint32_t)(CPL * sub);
+            uint32_t up[CPL], upi[CPL];
+#pragma unroll
+            for (int e = 0; e < CPL; e++) {
+                up[e] = cact ? rM[k0 + e + dsh] : INFW;     // past the row end: slots that exist, values nobody uses
+                upi[e] = cact ? rI[k0 + e + dsh] : INFW;
+            }
+            __syncthreads();                            // every lane has read its slots before any is overwritten
+            const uint32_t dleft = (uint32_t)row16_from<0x111>((int32_t)cdiag, (int32_t)up[CPL - 1]);
+            const bool more = __any(act && c0 + 64u < W);
+            if (more) cdiag = (uint32_t)__shfl((int)up[CPL - 1], lane | 15, 64);
+            int32_t av[CPL], a[CPL];
+            uint32_t ig[CPL];
+#pragma unroll
+            for (int e = 0; e < CPL; e++) {
+                const uint32_t diag = e == 0 ? dleft : up[e - 1];
+                const uint32_t tcd = up[e] & 7u;
+                const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);
+                const int32_t m = (int32_t)((sb << 6) + diag);
+                const int32_t u = (int32_t)up[e] + fc.cU;
+                const int32_t io = (int32_t)(up[e] & ~TAGS) + fc.cIO, ie = (int32_t)upi[e] + fc.cIE;
+                ig[e] = (uint32_t)min(io, ie);                          // bit 2: 1 = extend
+                const int32_t ic = (int32_t)ig[e] + (4 << 3);
+                av[e] = min(m, min(u, ic));                              // best of the moves that do not come from the left
+                a[e] = (int32_t)((uint32_t)av[e] & ~TAGS);
+            }
+            // prefix minima of a(j) - j * slope over the chunk's columns: inside the lane, then across the pair's 16 lanes
+            const int32_t kc = CPL * sub;
+            int32_t l1[CPL], l2[CPL];
+#pragma unroll
+            for (int e = 0; e < CPL; e++) {
+                const int32_t v1 = a[e] - (kc + e) * P, v2 = a[e] - (kc + e) * E;
+                l1[e] = e == 0 ? v1 : min(l1[e - 1], v1);
+                l2[e] = e == 0 ? v2 : min(l2[e - 1], v2);
+            }
+            const int32_t t1 = row16_scan_min(l1[CPL - 1], BIG), t2 = row16_scan_min(l2[CPL - 1], BIG);
+            const int32_t x1 = min(row16_from<0x111>(BIG, t1), carry1), x2 = min(row16_from<0x111>(BIG, t2), carry2);   // all columns left of this lane's
+            if (more) {
+                carry1 = min(__shfl(t1, lane | 15, 64), carry1) + 64 * P;
+                carry2 = min(__shfl(t2, lane | 15, 64), carry2) + 64 * E;
+            }
+            int32_t x[CPL], y[CPL];
+#pragma unroll
+            for (int e = 0; e < CPL; e++) {
+                const int32_t s1 = (e == 0 ? x1 : min(x1, l1[e - 1])) + (kc + e) * P;      // best a(j) + (k - j) * P over j < k
+                const int32_t s2 = (e == 0 ? x2 : min(x2, l2[e - 1])) + (kc + e) * E;      // best a(j) + (k - j) * E over j < k
+                x[e] = min(a[e], min(s1, s2 + OE - E));                  // score of M[k]
+                y[e] = y_by_e ? s2 + OE - E : s1 + OE - P;               // score of D[k]
+            }
+            const uint32_t xleft = (uint32_t)row16_from<0x111>((int32_t)xl, x[CPL - 1]);
+            const uint32_t yleft = (uint32_t)row16_from<0x111>((int32_t)yl, y[CPL - 1]);
+            if (more) { xl = (uint32_t)__shfl(x[CPL - 1], lane | 15, 64); yl = (uint32_t)__shfl(y[CPL - 1], lane | 15, 64); }
+            uint32_t ab = 0;
+#pragma unroll
+            for (int e = 0; e < CPL; e++) {
+                const uint32_t xp = e == 0 ? xleft : (uint32_t)x[e - 1], yp = e == 0 ? yleft : (uint32_t)y[e - 1];
+                const int32_t l = (int32_t)xp + fc.cL;
+                const int32_t dop = (int32_t)xp + fc.cDO, de = (int32_t)yp + fc.cDE;
+                const uint32_t dg = (uint32_t)min(dop, de);              // bit 1: 1 = extend
+                const int32_t dc = (int32_t)dg + (3 << 3);
+                const uint32_t best = (uint32_t)min(min(av[e], l), dc);
+                if (cact) {
+                    rM[k0 + e] = (best & ~TAGS) | (up[e] & 7u);
+                    rI[k0 + e] = ig[e] & ~TAGS;
+                }
+                // record byte: M arrow (bits 3..5) | I bit (bit 2) | D bit (bit 1)
+                ab |= ((best & 0x38u) | (ig[e] & 4u) | (dg & 2u)) << (8 * e);
+            }
+            const uint32_t dwi = (c0 >> 2) + (uint32_t)sub;
+            if (cact && dwi < nd) rec[roff + dwi] = ab;
+        }
+        if (act) {
+            if (sub == 0) rec[roff + nd] = word & ROW_META_MASK;
+            roff += nd + 1u;
+        }
+        __syncthreads();
+    }
+    if (have && sub == 0) {
+        const int32_t v = (int32_t)(rM[fslot] & ~TAGS) - (int32_t)Q * (128 << 6);
+        if (v >= UNREACH) d.status[p] = GBA_PAIR_UNREACHABLE;
+        d.dp_score[p] = v >> 6;
+    }
+}
+
 // ---------------------------------------------------------------- k_traceback
 // One lane per pair: from the end cell (Q, T) follow the arrows to (0, 0); merge diagonal runs
 // into blocks (ArrowPathToAlignment), count matches / mismatches / gaps and rescore the path
@@ -2250,6 +2435,8 @@ struct gba_ctx {
     uint32_t affine_top_slots = 0;   // affine gaps: a third lane class of this many slots (env GBA_AFFINE_TOP_SLOTS; 0: none).  Measured on 98 304 pairs
                                      // of 20 kb, band 16 (99 % of them fit 96 slots): none 221 GCUPS, 96 slots 212, 80 slots 190, 128 slots 187: three
                                      // lane-per-pair waves per CU are no faster than the narrow wave-per-pair kernel
+    uint32_t quad_affine_min = 10240;   // narrow affine wave class: this many pairs or more run four pairs per wave (fewer leave SIMDs
+                                        // without a wave that way; measured crossover between 8 192 and 12 288 pairs of 20 kb; env GBA_QUAD_AFFINE_MIN)
     uint32_t wave_pairs = 20480, wave_pairs_affine = 57344;   // batches (parts) smaller than this run wave-per-pair (env GBA_WAVE_PAIRS, GBA_WAVE_PAIRS_AFFINE)
     uint32_t score_a = 0, score_b = 0;   // largest cost of a row move / of a move along a row (k_meta's score-range check)
     uint32_t part_pairs = 122880;    // a batch of more than ~1.07 x this many pairs is run in staggered parts of about this
@@ -2453,6 +2640,7 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
                 else hipLaunchKernelGGL(k_fill_wide<4>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
             } else {
                 if (aff && d.prof) hipLaunchKernelGGL((k_fill_wide_affine<true, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+                else if (aff && cnt >= c->quad_affine_min) hipLaunchKernelGGL(k_fill_quad_affine, dim3((cnt + 3) / 4), dim3(64), 0, st, d, c->fc, (uint32_t)k, cnt);
                 else if (aff) hipLaunchKernelGGL((k_fill_wide_affine<true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else if (d.prof) hipLaunchKernelGGL((k_fill_wide<1, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else hipLaunchKernelGGL(k_fill_wide<1>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
@@ -2976,6 +3164,7 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
         }
         if (const char *e = getenv("GBA_PART_PAIRS")) c->part_pairs = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_WAVE_PAIRS")) c->wave_pairs = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char *e = getenv("GBA_QUAD_AFFINE_MIN")) c->quad_affine_min = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_WAVE_PAIRS_AFFINE")) c->wave_pairs_affine = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_AFFINE_TOP_SLOTS")) { const uint32_t v = (uint32_t)strtoul(e, nullptr, 10); if (v == 0 || (v > 64 && v <= 128)) c->affine_top_slots = v; }
         if (const char *e = getenv("GBA_SDP_TILE")) {

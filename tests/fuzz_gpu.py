@@ -248,7 +248,12 @@ def main():
     from blasr_amd import api, synth, _lib, emit
     from oracle import oracle
     rng = np.random.default_rng(args.seed)
-    ctx = api.Context(0)
+    # two contexts used in turn: the library's defaults, and one whose narrow affine wave class always runs four pairs per
+    # wave (by default only batches of 10 240 pairs or more do, which these rounds never reach)
+    os.environ["GBA_QUAD_AFFINE_MIN"] = "0"
+    ctx_quad = api.Context(0)
+    del os.environ["GBA_QUAD_AFFINE_MIN"]
+    ctxs = (api.Context(0), ctx_quad)
     pool = ThreadPoolExecutor(16)
     t_end = time.time() + args.seconds
     rounds = pairs_done = fails = unsupported = cigar_rounds = sdp_rounds = kband_rounds = qv_rounds = 0
@@ -256,6 +261,7 @@ def main():
     modes = {}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     while time.time() < t_end:
+        ctx = ctxs[(rounds >> 1) & 1]
         kw = random_scoring(rng, _lib)
         batch = random_adversarial(rng, util) if rng.random() < 0.35 else random_synth(rng, synth)
         n = int(batch["n_pairs"])

@@ -22,10 +22,13 @@ def api():
 def ctx(api, request):
     """Every test that takes this context runs twice: with batches of any size on the lane-per-pair
     kernels (rows too wide for them excepted), and with every batch on the wave-per-pair kernels
-    (the library itself sends batches too small to fill the GPU there)."""
-    old = {k: os.environ.get(k) for k in ("GBA_WAVE_PAIRS", "GBA_WAVE_PAIRS_AFFINE")}
+    (the library itself sends batches too small to fill the GPU there; the narrow affine wave class four pairs per wave,
+    which the library does for large batches only: the one-pair-per-wave instance is what tests/test_gpu_qv_guided.py, the
+    randomised driver and every other test file's small affine batches run)."""
+    old = {k: os.environ.get(k) for k in ("GBA_WAVE_PAIRS", "GBA_WAVE_PAIRS_AFFINE", "GBA_QUAD_AFFINE_MIN")}
     v = "0" if request.param == "lane-per-pair" else "4000000000"
     os.environ["GBA_WAVE_PAIRS"] = os.environ["GBA_WAVE_PAIRS_AFFINE"] = v
+    os.environ["GBA_QUAD_AFFINE_MIN"] = "0"
     c = api.Context(0, timing=True)
     for k, o in old.items():
         if o is None:
@@ -723,3 +726,32 @@ def test_maximum_width(ctx, api, oracle, synth, mode):
     ctx.set_scoring(api.make_scoring(band=512, max_band=512, **kw))
     pairs, blocks, rc = ctx.refine_host(batch)
     assert rc == 0 and (pairs["status"] == _lib.PAIR_TOO_WIDE).all() and (pairs["n_blk"] == 0).all()
+
+
+def test_four_pairs_per_wave_equals_one_pair_per_wave(api, oracle, synth, monkeypatch):
+    """The narrow affine wave class at a batch size where the library itself switches to four pairs per wave (10 243 pairs:
+    not a multiple of four, lengths that differ inside a wave): the same bytes as one pair per wave, and the first pairs
+    against the oracle."""
+    from blasr_amd import _lib
+    n = 10243
+    batch = synth.compact_blocks(synth.generate(n, read_len=700, len_jitter=500, seed=99))
+    kw = dict(mode=_lib.MODE_AFFINE, band=16, affine_open=7, affine_extend=2, stats_affine=1)
+    monkeypatch.setenv("GBA_WAVE_PAIRS_AFFINE", "4000000000")
+    outs = []
+    for quad_min in ("4000000000", None):
+        if quad_min is None:
+            monkeypatch.delenv("GBA_QUAD_AFFINE_MIN", raising=False)
+        else:
+            monkeypatch.setenv("GBA_QUAD_AFFINE_MIN", quad_min)
+        c = api.Context(0, timing=True)
+        c.set_scoring(api.make_scoring(**kw))
+        pairs, blocks, rc = c.refine_host(batch)
+        assert rc == 0 and int((pairs["status"] == 0).sum()) == n and int(c.timing()["wide_pairs"]) == n
+        outs.append((pairs.tobytes(), blocks.tobytes()))
+        c.close()
+    assert outs[0] == outs[1]
+    ores, oblk = oracle.align_batch(batch, oracle.make_params(**kw), 0, 24)
+    for p in range(24):
+        assert all(int(ores[p][f]) == int(pairs[p][f]) for f in util.FIELDS), p
+        kb = blocks[int(pairs[p]["blk_off"]):int(pairs[p]["blk_off"]) + int(pairs[p]["n_blk"])]
+        assert kb.tobytes() == np.asarray(oblk[p]).tobytes(), p
