@@ -335,7 +335,9 @@ def main():
     ops_cell, bytes_cell = OPS_PER_CELL[mode], BYTES_PER_CELL[mode]
     traffic = MEASURED_FILL_TRAFFIC.get((args.workload, n))
     wide = tm["wide_pairs"] * 2 > n               # most pairs ran wave-per-pair: the bulk kernel is k_fill_wide
-    kernel = ("k_fill_wide_affine" if affine else "k_fill_wide") if wide else "k_fill<%s>" % ("true" if affine else "false")
+    quad_min = int(os.environ.get("GBA_QUAD_AFFINE_MIN", "10240"))      # the library's switch to four pairs per wave (narrow affine class)
+    kernel = (("k_fill_quad_affine" if tm["wide_pairs"] >= quad_min and cfg["band"] <= 30 else "k_fill_wide_affine") if affine else "k_fill_wide") \
+        if wide else "k_fill<%s>" % ("true" if affine else "false")
     out = {
         "metric": "banded-DP GCUPS (guided banded alignment, refine stage)",
         "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world,

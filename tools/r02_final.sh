@@ -14,3 +14,8 @@ timeout -k 10 300 python -u tools/kband_time.py > gpurun_out/r02_final_kband_tim
 grep -v amdgpu gpurun_out/r02_final_kband_time.log
 GBA_WAVE_PAIRS=1000000 timeout -k 10 300 python -u tools/qv_time.py > gpurun_out/r02_final_qv_time.log 2>&1 || exit 1
 grep -v amdgpu gpurun_out/r02_final_qv_time.log
+bash tools/r02_workloads.sh > gpurun_out/r02_final_workloads.log 2>&1 || { tail -5 gpurun_out/r02_final_workloads.log; exit 1; }
+cat gpurun_out/r02_final_workloads.log
+# two ranks on this one GPU over gloo: the sharded path bench.py --gpus N takes (common read set, merge in input order)
+GBA_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 1 --pairs 65536 > gpurun_out/r02_final_two_ranks.json 2> gpurun_out/r02_final_two_ranks.err || { tail -5 gpurun_out/r02_final_two_ranks.err; exit 1; }
+cut -c1-400 gpurun_out/r02_final_two_ranks.json
