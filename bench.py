@@ -336,7 +336,7 @@ def main():
     traffic = MEASURED_FILL_TRAFFIC.get((args.workload, n))
     wide = tm["wide_pairs"] * 2 > n               # most pairs ran wave-per-pair: the bulk kernel is k_fill_wide
     quad_min = int(os.environ.get("GBA_QUAD_AFFINE_MIN", "10240"))      # the library's switch to four pairs per wave (narrow affine class)
-    kernel = (("k_fill_quad_affine" if tm["wide_pairs"] >= quad_min and cfg["band"] <= 30 else "k_fill_wide_affine") if affine else "k_fill_wide") \
+    kernel = (("k_fill_quad_affine" if tm["wide_pairs"] >= quad_min and cfg["band"] <= 30 else "k_fill_wide_affine") if affine else ("k_fill_wide_cols" if cfg["band"] > 30 else "k_fill_wide<1>")) \
         if wide else "k_fill<%s>" % ("true" if affine else "false")
     out = {
         "metric": "banded-DP GCUPS (guided banded alignment, refine stage)",

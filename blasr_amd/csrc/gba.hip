@@ -52,7 +52,7 @@ constexpr uint32_t MAX_COLS = 1u << 20;
 // Classes of the lane-per-pair fill kernel: a pair's class is the smallest LDS row buffer
 // (32 << class slots) that holds its widest "shift + width".  Each non-empty class is one launch.
 constexpr int NCLS = 5;                      // lane-per-pair classes of 32, 64, 128 slots, then the two wave-per-pair classes
-constexpr int CLS_WIDE = NCLS - 1;           // pairs too wide for everything else: k_fill_wide<4> / k_fill_wide_affine<false>
+constexpr int CLS_WIDE = NCLS - 1;           // pairs too wide for everything else: k_fill_wide_cols (k_fill_wide<4> with a cost profile) / k_fill_wide_affine<false>
 constexpr int CLS_WNARROW = NCLS - 2;        // wave-per-pair with a small ring (shift + width <= WN_SPAN): pairs a little too wide for
                                              // the lane classes, and ALL pairs of a batch too small to fill the GPU one lane per pair
 constexpr uint32_t WN_SPAN = 124;
@@ -1040,6 +1040,114 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t 
                     if ((lane & 15) == 15 && dwi < nd) rec[roff + dwi] = (uint32_t)ab;
                 }
             }
+        }
+        if (lane == 0) rec[roff + nd] = word & ROW_META_MASK;
+        roff += nd + 1u;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        const int32_t v = (int32_t)(ring[fslot] & ~TAGS) - (int32_t)Q * (128 << 5);
+        if (v >= UNREACH) d.status[p] = GBA_PAIR_UNREACHABLE;
+        d.dp_score[p] = v >> 5;
+    }
+}
+
+// ---------------------------------------------------------------- k_fill_wide_cols
+// The widest class with linear gaps and matrix costs: k_fill_wide<4> with the 256 columns in flight dealt to the lanes
+// four NEIGHBOURING columns each instead of four chunks of 64.  The deletion chain then needs one wave scan per 256
+// columns (a running minimum over the lane's own four, the scan over the lanes' totals, and the exclusive prefix applied
+// to the four) where the chunked form ran four; a column's diagonal predecessor is the lane's own previous value for
+// three columns of four; and the four 2-bit arrows of a lane are one byte of a record dword that four lanes put
+// together in two steps.  Rows of 201 cells (band 100) take 0.3 of the instructions.  Words, tie-break and records are
+// those of k_fill_wide.
+__global__ __launch_bounds__(64) void k_fill_wide_cols(Dev d, FillConst fc, uint32_t cls)
+{
+    constexpr int CPL = 4, SPAN = 64 * CPL;
+    __shared__ uint32_t ring[WIDE_RING];
+    __shared__ uint32_t sbuf[WIDE_SBUF];
+    __shared__ uint32_t tab[LDS_TAB];
+    static_assert(WIDE_RING >= 2048 + SPAN, "lanes run up to SPAN - 1 columns past the row end");
+    constexpr uint32_t TAGS = 31u;
+    constexpr int32_t BIG = 0x60000000;
+    const int lane = threadIdx.x;
+    if (lane < 10) tab[lane] = fc.mrow[lane];
+    const uint32_t p = d.order[d.plan->cls_base[cls] + blockIdx.x];
+    const uint32_t Q = d.Q[p];
+    const uint32_t fslot = d.T[p] - d.lo_last[p];
+    const uint32_t *st = d.stream + d.word_off[p];
+    const uint32_t wcap = d.wcap[p];
+    uint32_t *rec = d.rec + d.rec_off[p];
+    const int32_t D = fc.del * 32;
+    const int32_t codeL = fc.cL - D;
+    uint32_t spos = 0, sload = 0;
+    uint32_t W = 0, Wp = 0, dsh = 0, roff = 0;
+    __syncthreads();
+    for (uint32_t r = 0; r <= Q; r++) {
+        while (sload - spos < (uint32_t)WIDE_SBUF / 2 && sload < wcap) {
+            const uint32_t x = sload + lane;
+            const uint32_t v = x < wcap ? st[x] : 0u;
+            sbuf[x & (WIDE_SBUF - 1)] = v;
+            sload += 64;
+        }
+        __syncthreads();
+        const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)sbuf[spos & (WIDE_SBUF - 1)]);
+        Wp = W;
+        W = word & ROW_W_MASK; dsh = (word >> 13) & 1023u;
+        const uint32_t qcode = (word >> 10) & 7u;
+        const uint32_t mlo = tab[qcode * 2], mhi = tab[qcode * 2 + 1];
+        const uint32_t tot = dsh + W;
+        const uint32_t nnew = tot > Wp ? tot - Wp : 0u;
+        for (uint32_t x = lane; x < nnew; x += 64) {
+            uint32_t code;
+            if (x < 3u) code = (word >> (23u + 3u * x)) & 7u;
+            else {
+                const uint32_t e = (x - 3u) >> 3, rr = (x - 3u) & 7u;
+                code = (sbuf[(spos + 1u + e) & (WIDE_SBUF - 1)] >> (3u * rr)) & 7u;
+            }
+            ring[Wp + x] = INFW | code;
+        }
+        spos += 1u + (nnew > 3u ? (nnew + 4u) >> 3 : 0u);
+        __syncthreads();
+        uint32_t cdiag = dsh >= 1u && dsh - 1u < Wp ? ring[dsh - 1u] : INFW;
+        int32_t hc = r == 0 ? -D : (int32_t)INFW;       // row 0: column j costs j deletions
+        const uint32_t nd = (W + 15u) >> 4;
+        const int32_t kk = CPL * lane;                  // this lane's first column inside the span
+        for (uint32_t c0 = 0; c0 < W; c0 += SPAN) {
+            const uint32_t k0 = c0 + (uint32_t)kk;
+            uint32_t up[CPL];
+#pragma unroll
+            for (int e = 0; e < CPL; e++) up[e] = ring[k0 + e + dsh];       // past the row end: slots that exist, values nobody uses
+            __syncthreads();                            // every lane has read its slots before any is overwritten
+            const uint32_t dleft = (uint32_t)__builtin_amdgcn_update_dpp((int32_t)cdiag, (int32_t)up[CPL - 1], 0x138, 0xf, 0xf, false);
+            cdiag = (uint32_t)__builtin_amdgcn_readlane((int32_t)up[CPL - 1], 63);
+            int32_t xv[CPL], run[CPL];
+#pragma unroll
+            for (int e = 0; e < CPL; e++) {
+                const uint32_t diag = e == 0 ? dleft : up[e - 1];
+                const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, up[e] & 7u);
+                const int32_t m = (int32_t)((sb << 5) + diag);
+                const int32_t u = (int32_t)up[e] + fc.cU;
+                xv[e] = min(m, u);                      // best of the two moves from the previous row
+                const int32_t v = (int32_t)((uint32_t)xv[e] & ~TAGS) - (kk + e) * D;
+                run[e] = e == 0 ? v : min(run[e - 1], v);
+            }
+            const int32_t incl = wave_scan_min(run[CPL - 1], BIG);
+            const int32_t excl = __builtin_amdgcn_update_dpp(BIG, incl, 0x138, 0xf, 0xf, false);      // every column left of this lane's four
+            uint32_t ab = 0;
+#pragma unroll
+            for (int e = 0; e < CPL; e++) {
+                const int32_t before = e == 0 ? excl : min(excl, run[e - 1]);
+                const int32_t lc = min(before + (kk + e) * D, hc + (kk + e + 1) * D) + codeL;
+                const uint32_t best = (uint32_t)min(xv[e], lc);
+                ring[k0 + e] = (up[e] & TAGS) | (best & ~TAGS);
+                ab |= ((best >> 3) & 3u) << (2 * (CPL * (lane & 3) + e));
+            }
+            hc = min(__builtin_amdgcn_readlane(incl, 63) + (SPAN - 1) * D, hc + SPAN * D);
+            // arrows: 2 bits per column, 16 columns = four lanes per dword
+            ab |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)ab, 0x111, 0xf, 0xf, false);
+            ab |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)ab, 0x112, 0xf, 0xf, false);
+            const uint32_t dwi = (c0 >> 4) + ((uint32_t)lane >> 2);
+            if ((lane & 3) == 3 && dwi < nd) rec[roff + dwi] = ab;
         }
         if (lane == 0) rec[roff + nd] = word & ROW_META_MASK;
         roff += nd + 1u;
@@ -2637,7 +2745,7 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
                 if (aff && d.prof) hipLaunchKernelGGL((k_fill_wide_affine<false, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else if (aff) hipLaunchKernelGGL((k_fill_wide_affine<false>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else if (d.prof) hipLaunchKernelGGL((k_fill_wide<4, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
-                else hipLaunchKernelGGL(k_fill_wide<4>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+                else hipLaunchKernelGGL(k_fill_wide_cols, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
             } else {
                 if (aff && d.prof) hipLaunchKernelGGL((k_fill_wide_affine<true, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else if (aff && cnt >= c->quad_affine_min) hipLaunchKernelGGL(k_fill_quad_affine, dim3((cnt + 3) / 4), dim3(64), 0, st, d, c->fc, (uint32_t)k, cnt);
