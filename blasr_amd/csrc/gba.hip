@@ -1731,8 +1731,9 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
     int32_t score = 0;
     uint32_t budget = (Q + T + 2u) * (AFF ? 3u : 1u);   // affine paths spend an extra step on every gap-state change
     uint32_t state = 0;                                 // affine: 0 match state, 1 insertion gap, 2 deletion gap
-    bool ok = true, done = false;
+    bool ok = true, done = false, look_ahead = true;
     int32_t pend_v = 0;
+    int32_t lane_score = 0, lane_x0 = 0, lane_x1 = 0;   // substitution costs of the runs taken lanes side by side, summed over the lanes at the end
     int32_t ptr = (int32_t)uni(d.recdw[p]) - 1;         // meta dword of the current row
     while (!done) {
         // refill: records [rb, rb + WT_WIN) ending at ptr, target codes [jb, jb + WT_TC) ending at column j
@@ -1757,6 +1758,50 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
         for (;;) {
             if ((i | j) == 0u) { done = true; break; }
             if (ptr - (int32_t)n - 1 < rb || (int32_t)j - 1 < jb) break;          // next refill
+            if (look_ahead && state == 0u) {
+                // A run of diagonal moves in one go: lane t looks at the cell t rows up and t columns left, on the
+                // assumption that the rows in between are as wide as this one (so their records are as long); every
+                // lane checks its row's width, its own column range and its arrow, and the run ends at the first lane
+                // that finds anything else.  Most of a path is such runs; single steps take the scalar code below.
+                const uint32_t stride = n + 1u;
+                const int32_t mt = ptr - (int32_t)((uint32_t)lane * stride);          // meta dword of row i - lane
+                const bool inwin = (uint32_t)lane < i && (uint32_t)lane < j && mt - (int32_t)stride >= rb && (int32_t)j - lane - 1 >= jb;
+                const uint32_t gw_t = inwin ? win[mt - rb] : 0u;
+                const bool same = inwin && (gw_t & ROW_W_MASK) == W;
+                const uint32_t dsh_t = same ? (gw_t >> 13) & 1023u : 0u;
+                const uint32_t dsum = wave_scan_sum(dsh_t);
+                const uint32_t lo_t = lo - (dsum - dsh_t);                            // first column of row i - lane
+                const uint32_t k_t = j - (uint32_t)lane - lo_t;
+                const bool incol = same && k_t < W;
+                const uint32_t aw_t = incol ? win[mt - (int32_t)n + (int32_t)(k_t >> CSHIFT) - rb] : ~0u;
+                const uint32_t cell_t = aw_t >> ((k_t & CMASK) * BITS);
+                const bool diag_t = incol && (AFF ? ((cell_t >> 3) & 7u) == 0u : (cell_t & 3u) == 0u);
+                const unsigned long long okm = __ballot(diag_t);
+                uint32_t L = okm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okm);
+                L = min(L, budget);
+                if (L > 0u) {
+                    const bool mine = (uint32_t)lane < L;
+                    const uint32_t qb_t = (gw_t >> 10) & 7u;
+                    const uint32_t tb_t = mine ? (uint32_t)tcw8[(int32_t)j - lane - jb] - 1u : 0u;
+                    if (mine) {
+                        lane_score += sub[qb_t * 5 + tb_t];
+                        if (nx > 0) lane_x0 += sub[25 + qb_t * 5 + tb_t];
+                        if (nx > 1) lane_x1 += sub[50 + qb_t * 5 + tb_t];
+                    }
+                    nM += (uint32_t)__popcll(__ballot(mine && qb_t == tb_t));
+                    run += L; ndiag += L; prev_op = 0; budget -= L;
+                    i -= L; j -= L;
+                    // the first column after L rows: the exclusive prefix at lane L (lane 63's inclusive one for a full run)
+                    lo = L < 64u ? (uint32_t)__builtin_amdgcn_readlane((int32_t)lo_t, (int)L)
+                                 : (uint32_t)__builtin_amdgcn_readlane((int32_t)(lo_t - dsh_t), 63);
+                    ptr -= (int32_t)(L * stride);
+                    gw = uni(win[ptr - rb]);
+                    W = gw & ROW_W_MASK; n = (W + CMASK) >> CSHIFT;
+                    look_ahead = L == 64u;            // a run that ended inside the wave ended at a move for the scalar code
+                    continue;
+                }
+            }
+            look_ahead = true;
             const uint32_t k = j - lo;
             if (k >= W || budget-- == 0u) { ok = false; done = true; break; }
             const int32_t up = ptr - (int32_t)n - 1;                 // meta dword of row i - 1
@@ -1812,6 +1857,13 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
     }
     score += (int32_t)uni((uint32_t)pend_v);
     xs0 += (int32_t)uni((uint32_t)xp0); xs1 += (int32_t)uni((uint32_t)xp1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lane_score += __shfl_xor(lane_score, o, 64);
+        lane_x0 += __shfl_xor(lane_x0, o, 64);
+        lane_x1 += __shfl_xor(lane_x1, o, 64);
+    }
+    score += lane_score; xs0 += lane_x0; xs1 += lane_x1;
     if (run) { outp -= 3; if (lane == 0) { outp[0] = i; outp[1] = j; outp[2] = run; } nb++; }
     if (lane != 0) return;
     gba_pair_result &R = res[p];
