@@ -2595,6 +2595,8 @@ struct gba_ctx {
     uint32_t affine_top_slots = 0;   // affine gaps: a third lane class of this many slots (env GBA_AFFINE_TOP_SLOTS; 0: none).  Measured on 98 304 pairs
                                      // of 20 kb, band 16 (99 % of them fit 96 slots): none 221 GCUPS, 96 slots 212, 80 slots 190, 128 slots 187: three
                                      // lane-per-pair waves per CU are no faster than the narrow wave-per-pair kernel
+    uint32_t tb_wave_max = 6144;         // a batch that ran on the wave kernels altogether with at most this many narrow-class pairs is walked
+                                         // back one wave per pair too (measured crossover: 6 600 pairs of 10 kb, 10 600 of 20 kb affine; env GBA_TB_WAVE_MAX)
     uint32_t quad_affine_min = 10240;   // narrow affine wave class: this many pairs or more run four pairs per wave (fewer leave SIMDs
                                         // without a wave that way; measured crossover between 8 192 and 12 288 pairs of 20 kb; env GBA_QUAD_AFFINE_MIN)
     uint32_t wave_pairs = 20480, wave_pairs_affine = 57344;   // batches (parts) smaller than this run wave-per-pair (env GBA_WAVE_PAIRS, GBA_WAVE_PAIRS_AFFINE)
@@ -2820,7 +2822,10 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
     for (int a = 0; a < NAUXS; a++)
         if (used[a] && !wave_on_aux[a]) HIPCHK(c, hipStreamWaitEvent(s, sl.ev_join[a], 0));
     if (wave_on_main[CLS_WIDE]) launch_tb(CLS_WIDE, s);
-    if (pl.cls_base[CLS_WIDE] > 0) launch_tb_lanes(s);
+    // a batch that ran on the wave kernels altogether and leaves the lane-per-pair traceback with too few waves to hide
+    // its walk (one dependent chain per pair, however few pairs): the narrow wave class is walked one wave per pair too
+    if (pl.cls_base[CLS_WNARROW] == 0 && pl.cls_count[CLS_WNARROW] > 0 && pl.cls_count[CLS_WNARROW] <= c->tb_wave_max) launch_tb(CLS_WNARROW, s);
+    else if (pl.cls_base[CLS_WIDE] > 0) launch_tb_lanes(s);
     HIPCHK(c, hipGetLastError());
     for (int a = 0; a < NAUXS; a++)
         if (used[a] && wave_on_aux[a]) HIPCHK(c, hipStreamWaitEvent(s, sl.ev_join[a], 0));
@@ -3324,6 +3329,7 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
         }
         if (const char *e = getenv("GBA_PART_PAIRS")) c->part_pairs = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_WAVE_PAIRS")) c->wave_pairs = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char *e = getenv("GBA_TB_WAVE_MAX")) c->tb_wave_max = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_QUAD_AFFINE_MIN")) c->quad_affine_min = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_WAVE_PAIRS_AFFINE")) c->wave_pairs_affine = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_AFFINE_TOP_SLOTS")) { const uint32_t v = (uint32_t)strtoul(e, nullptr, 10); if (v == 0 || (v > 64 && v <= 128)) c->affine_top_slots = v; }

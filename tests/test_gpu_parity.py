@@ -25,10 +25,13 @@ def ctx(api, request):
     (the library itself sends batches too small to fill the GPU there; the narrow affine wave class four pairs per wave,
     which the library does for large batches only: the one-pair-per-wave instance is what tests/test_gpu_qv_guided.py, the
     randomised driver and every other test file's small affine batches run)."""
-    old = {k: os.environ.get(k) for k in ("GBA_WAVE_PAIRS", "GBA_WAVE_PAIRS_AFFINE", "GBA_QUAD_AFFINE_MIN")}
+    old = {k: os.environ.get(k) for k in ("GBA_WAVE_PAIRS", "GBA_WAVE_PAIRS_AFFINE", "GBA_QUAD_AFFINE_MIN", "GBA_TB_WAVE_MAX")}
     v = "0" if request.param == "lane-per-pair" else "4000000000"
     os.environ["GBA_WAVE_PAIRS"] = os.environ["GBA_WAVE_PAIRS_AFFINE"] = v
     os.environ["GBA_QUAD_AFFINE_MIN"] = "0"
+    # the narrow wave class walked back by the lane-per-pair traceback, as in large batches; small batches on a default
+    # context (the other test files, the randomised driver) are walked back one wave per pair
+    os.environ["GBA_TB_WAVE_MAX"] = "0"
     c = api.Context(0, timing=True)
     for k, o in old.items():
         if o is None:
@@ -755,3 +758,22 @@ def test_four_pairs_per_wave_equals_one_pair_per_wave(api, oracle, synth, monkey
         assert all(int(ores[p][f]) == int(pairs[p][f]) for f in util.FIELDS), p
         kb = blocks[int(pairs[p]["blk_off"]):int(pairs[p]["blk_off"]) + int(pairs[p]["n_blk"])]
         assert kb.tobytes() == np.asarray(oblk[p]).tobytes(), p
+
+
+@pytest.mark.parametrize("kw", [dict(band=10), dict(band=40, tie_break=1), dict(mode=1, band=16, affine_open=6, affine_extend=1, stats_affine=1)])
+def test_small_batches_walk_back_one_wave_per_pair(api, oracle, synth, monkeypatch, kw):
+    """A batch small enough to run on the wave-per-pair kernels altogether is also traced back one wave per pair (diagonal
+    runs taken lanes side by side); the same bytes as the lane-per-pair traceback gives, and the oracle's results."""
+    batch = synth.compact_blocks(synth.generate(300, read_len=900, len_jitter=700, seed=17))
+    outs = []
+    for tb_max in ("0", None):
+        if tb_max is None:
+            monkeypatch.delenv("GBA_TB_WAVE_MAX", raising=False)
+        else:
+            monkeypatch.setenv("GBA_TB_WAVE_MAX", tb_max)
+        c = api.Context(0, timing=True)
+        pairs, blocks = _run(c, api, oracle, batch, **kw)
+        assert int(c.timing()["wide_pairs"]) == 300
+        outs.append((pairs.tobytes(), blocks.tobytes()))
+        c.close()
+    assert outs[0] == outs[1]
