@@ -1779,25 +1779,49 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
                 const unsigned long long okm = __ballot(diag_t);
                 uint32_t L = okm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okm);
                 L = min(L, budget);
-                if (L > 0u) {
-                    const bool mine = (uint32_t)lane < L;
-                    const uint32_t qb_t = (gw_t >> 10) & 7u;
-                    const uint32_t tb_t = mine ? (uint32_t)tcw8[(int32_t)j - lane - jb] - 1u : 0u;
-                    if (mine) {
-                        lane_score += sub[qb_t * 5 + tb_t];
-                        if (nx > 0) lane_x0 += sub[25 + qb_t * 5 + tb_t];
-                        if (nx > 1) lane_x1 += sub[50 + qb_t * 5 + tb_t];
+                // the move behind the run goes along if the lane that ended it sees a plain insertion or deletion arrow
+                // (its row has this row's width and its column lies inside: the row above it is in the window)
+                uint32_t gap = 0;                     // 0 none, 1 up, 2 left
+                if (L < 64u && budget > L) {
+                    const uint32_t a_t = AFF ? (cell_t >> 3) & 7u : cell_t & 3u;
+                    const uint32_t mv_t = incol && !diag_t ? (a_t == tc_.codeU ? 1u : a_t == tc_.codeL ? 2u : 0u) : 0u;
+                    gap = (uint32_t)__builtin_amdgcn_readlane((int32_t)mv_t, (int)L);
+                }
+                if (L > 0u || gap != 0u) {
+                    if (L > 0u) {
+                        const bool mine = (uint32_t)lane < L;
+                        const uint32_t qb_t = (gw_t >> 10) & 7u;
+                        const uint32_t tb_t = mine ? (uint32_t)tcw8[(int32_t)j - lane - jb] - 1u : 0u;
+                        if (mine) {
+                            lane_score += sub[qb_t * 5 + tb_t];
+                            if (nx > 0) lane_x0 += sub[25 + qb_t * 5 + tb_t];
+                            if (nx > 1) lane_x1 += sub[50 + qb_t * 5 + tb_t];
+                        }
+                        nM += (uint32_t)__popcll(__ballot(mine && qb_t == tb_t));
+                        run += L; ndiag += L; prev_op = 0; budget -= L;
+                        i -= L; j -= L;
+                        // the first column after L rows: the exclusive prefix at lane L (lane 63's inclusive one for a full run)
+                        lo = L < 64u ? (uint32_t)__builtin_amdgcn_readlane((int32_t)lo_t, (int)L)
+                                     : (uint32_t)__builtin_amdgcn_readlane((int32_t)(lo_t - dsh_t), 63);
+                        ptr -= (int32_t)(L * stride);
                     }
-                    nM += (uint32_t)__popcll(__ballot(mine && qb_t == tb_t));
-                    run += L; ndiag += L; prev_op = 0; budget -= L;
-                    i -= L; j -= L;
-                    // the first column after L rows: the exclusive prefix at lane L (lane 63's inclusive one for a full run)
-                    lo = L < 64u ? (uint32_t)__builtin_amdgcn_readlane((int32_t)lo_t, (int)L)
-                                 : (uint32_t)__builtin_amdgcn_readlane((int32_t)(lo_t - dsh_t), 63);
-                    ptr -= (int32_t)(L * stride);
+                    if (gap != 0u) {
+                        if (run) {
+                            outp -= 3;
+                            if (lane == 0) { outp[0] = i; outp[1] = j; outp[2] = run; }
+                            nb++; run = 0;
+                        }
+                        nopen += prev_op != gap ? 1u : 0u;
+                        prev_op = gap; budget--;
+                        if (gap == 1u) {
+                            i--;
+                            lo -= (uint32_t)__builtin_amdgcn_readlane((int32_t)dsh_t, (int)L);
+                            ptr -= (int32_t)stride;
+                        } else j--;
+                    }
                     gw = uni(win[ptr - rb]);
                     W = gw & ROW_W_MASK; n = (W + CMASK) >> CSHIFT;
-                    look_ahead = L == 64u;            // a run that ended inside the wave ended at a move for the scalar code
+                    look_ahead = L == 64u || gap != 0u;       // a run that ended at anything else ended at a move for the scalar code
                     continue;
                 }
             }
