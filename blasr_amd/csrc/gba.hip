@@ -976,16 +976,21 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t 
         const uint32_t tot = dsh + W;
         const uint32_t nnew = tot > Wp ? tot - Wp : 0u;
         // entering columns: INFW words carrying the column's base code
-        for (uint32_t x = lane; x < nnew; x += 64) {
-            uint32_t code;
-            if (x < 3u) code = (word >> (23u + 3u * x)) & 7u;
-            else {
-                const uint32_t e = (x - 3u) >> 3, rr = (x - 3u) & 7u;
-                code = (sbuf[(spos + 1u + e) & (WIDE_SBUF - 1)] >> (3u * rr)) & 7u;
+        if (nnew <= 3u) {                               // nearly every row: the entering codes sit in the row word itself
+            if ((uint32_t)lane < nnew) ring[Wp + lane] = INFW | ((word >> (23u + 3u * (uint32_t)lane)) & 7u);
+            spos += 1u;
+        } else {
+            for (uint32_t x = lane; x < nnew; x += 64) {
+                uint32_t code;
+                if (x < 3u) code = (word >> (23u + 3u * x)) & 7u;
+                else {
+                    const uint32_t e = (x - 3u) >> 3, rr = (x - 3u) & 7u;
+                    code = (sbuf[(spos + 1u + e) & (WIDE_SBUF - 1)] >> (3u * rr)) & 7u;
+                }
+                ring[Wp + x] = INFW | code;
             }
-            ring[Wp + x] = INFW | code;
+            spos += 1u + ((nnew + 4u) >> 3);
         }
-        spos += 1u + (nnew > 3u ? (nnew + 4u) >> 3 : 0u);
         __syncthreads();
         // carries into the first chunk: the diagonal predecessor of column 0 and "the cell left of it"
         uint32_t cdiag = dsh >= 1u && dsh - 1u < Wp ? ring[dsh - 1u] : INFW;
@@ -1097,16 +1102,21 @@ __global__ __launch_bounds__(64) void k_fill_wide_cols(Dev d, FillConst fc, uint
         const uint32_t mlo = tab[qcode * 2], mhi = tab[qcode * 2 + 1];
         const uint32_t tot = dsh + W;
         const uint32_t nnew = tot > Wp ? tot - Wp : 0u;
-        for (uint32_t x = lane; x < nnew; x += 64) {
-            uint32_t code;
-            if (x < 3u) code = (word >> (23u + 3u * x)) & 7u;
-            else {
-                const uint32_t e = (x - 3u) >> 3, rr = (x - 3u) & 7u;
-                code = (sbuf[(spos + 1u + e) & (WIDE_SBUF - 1)] >> (3u * rr)) & 7u;
+        if (nnew <= 3u) {                               // nearly every row: the entering codes sit in the row word itself
+            if ((uint32_t)lane < nnew) ring[Wp + lane] = INFW | ((word >> (23u + 3u * (uint32_t)lane)) & 7u);
+            spos += 1u;
+        } else {
+            for (uint32_t x = lane; x < nnew; x += 64) {
+                uint32_t code;
+                if (x < 3u) code = (word >> (23u + 3u * x)) & 7u;
+                else {
+                    const uint32_t e = (x - 3u) >> 3, rr = (x - 3u) & 7u;
+                    code = (sbuf[(spos + 1u + e) & (WIDE_SBUF - 1)] >> (3u * rr)) & 7u;
+                }
+                ring[Wp + x] = INFW | code;
             }
-            ring[Wp + x] = INFW | code;
+            spos += 1u + ((nnew + 4u) >> 3);
         }
-        spos += 1u + (nnew > 3u ? (nnew + 4u) >> 3 : 0u);
         __syncthreads();
         uint32_t cdiag = dsh >= 1u && dsh - 1u < Wp ? ring[dsh - 1u] : INFW;
         int32_t hc = r == 0 ? -D : (int32_t)INFW;       // row 0: column j costs j deletions
@@ -1249,17 +1259,25 @@ __global__ __launch_bounds__(64) void k_fill_wide_affine(Dev d, FillConst fc, ui
         const uint32_t mlo = tab[qcode * 2], mhi = tab[qcode * 2 + 1];
         const uint32_t tot = dsh + W;
         const uint32_t nnew = tot > Wp ? tot - Wp : 0u;
-        for (uint32_t x = lane; x < nnew; x += 64) {
-            uint32_t code;
-            if (x < 3u) code = (word >> (23u + 3u * x)) & 7u;
-            else {
-                const uint32_t e = (x - 3u) >> 3, rr = (x - 3u) & 7u;
-                code = (sbuf[(spos + 1u + e) & (WIDE_SBUF - 1)] >> (3u * rr)) & 7u;
+        if (nnew <= 3u) {                               // nearly every row: the entering codes sit in the row word itself
+            if ((uint32_t)lane < nnew) {
+                ringM[Wp + lane] = INFW | ((word >> (23u + 3u * (uint32_t)lane)) & 7u);
+                ringI[Wp + lane] = INFW;
             }
-            ringM[Wp + x] = INFW | code;
-            ringI[Wp + x] = INFW;
+            spos += 1u;
+        } else {
+            for (uint32_t x = lane; x < nnew; x += 64) {
+                uint32_t code;
+                if (x < 3u) code = (word >> (23u + 3u * x)) & 7u;
+                else {
+                    const uint32_t e = (x - 3u) >> 3, rr = (x - 3u) & 7u;
+                    code = (sbuf[(spos + 1u + e) & (WIDE_SBUF - 1)] >> (3u * rr)) & 7u;
+                }
+                ringM[Wp + x] = INFW | code;
+                ringI[Wp + x] = INFW;
+            }
+            spos += 1u + ((nnew + 4u) >> 3);
         }
-        spos += 1u + (nnew > 3u ? (nnew + 4u) >> 3 : 0u);
         __syncthreads();
         // row 0: the diagonal candidate of cell (0,0) costs exactly 0
         uint32_t cdiag = r == 0 ? (uint32_t)fc.diag0 : dsh >= 1u && dsh - 1u < Wp ? ringM[dsh - 1u] : INFW;
@@ -1418,16 +1436,23 @@ __global__ __launch_bounds__(64) void k_fill_quad_affine(Dev d, FillConst fc, ui
         const uint32_t qcode = (word >> 10) & 7u;
         const uint32_t mlo = tab[qcode * 2], mhi = tab[qcode * 2 + 1];
         // entering columns: INFW words carrying the column's base code
-        for (uint32_t x = (uint32_t)sub; __any(x < nnew); x += 16) {
-            if (x < nnew) {
-                uint32_t code;
-                if (x < 3u) code = (word >> (23u + 3u * x)) & 7u;
-                else {
-                    const uint32_t e = (x - 3u) >> 3, rr = (x - 3u) & 7u;
-                    code = (sb_[(spos + 1u + e) & (WN_SBUF - 1)] >> (3u * rr)) & 7u;
+        if (!__any(nnew > 3u)) {                        // nearly every row: the entering codes sit in the row words themselves
+            if ((uint32_t)sub < nnew) {
+                rM[Wp + sub] = INFW | ((word >> (23u + 3u * (uint32_t)sub)) & 7u);
+                rI[Wp + sub] = INFW;
+            }
+        } else {
+            for (uint32_t x = (uint32_t)sub; __any(x < nnew); x += 16) {
+                if (x < nnew) {
+                    uint32_t code;
+                    if (x < 3u) code = (word >> (23u + 3u * x)) & 7u;
+                    else {
+                        const uint32_t e = (x - 3u) >> 3, rr = (x - 3u) & 7u;
+                        code = (sb_[(spos + 1u + e) & (WN_SBUF - 1)] >> (3u * rr)) & 7u;
+                    }
+                    rM[Wp + x] = INFW | code;
+                    rI[Wp + x] = INFW;
                 }
-                rM[Wp + x] = INFW | code;
-                rI[Wp + x] = INFW;
             }
         }
         if (act) spos += 1u + (nnew > 3u ? (nnew + 4u) >> 3 : 0u);
