@@ -2757,7 +2757,14 @@ Dev sub_dev(const Dev &g, uint32_t p0, uint32_t cnt, Slot &sl)
 int phase_sizes(gba_ctx *c, Slot &sl, const Dev &d)
 {
     const gba_scoring &sc = c->sc;
-    hipLaunchKernelGGL(k_meta, dim3((d.n + 255) / 256), dim3(256), 0, sl.s, d, sc.mode, sc.kband_k, c->score_a, c->score_b,
+    // a batch with a cost profile takes its per-base costs from there, each within +-127 (+-63 with affine gaps, where open +
+    // extend, already in score_a / score_b, may be larger than that): the bound is the profile's range, not the matrix's
+    uint32_t sa = c->score_a, sb = c->score_b;
+    if (d.prof) {
+        const uint32_t pmax = sc.mode == GBA_MODE_AFFINE ? 63u : 127u;
+        sa = sa > pmax ? sa : pmax; sb = sb > pmax ? sb : pmax;
+    }
+    hipLaunchKernelGGL(k_meta, dim3((d.n + 255) / 256), dim3(256), 0, sl.s, d, sc.mode, sc.kband_k, sa, sb,
                        (uint32_t)(UNREACH >> (sc.mode == GBA_MODE_AFFINE ? 6 : 5)));
     hipLaunchKernelGGL(k_scan3, dim3(1), dim3(SCAN_T), 0, sl.s, d);
     HIPCHK(c, hipGetLastError());

@@ -32,6 +32,9 @@ struct MappingParameters {
     bool useGuidedAlign = true, refineAlignments = true, sortRefinedAlignments = true;
     bool doGlobalAlignment = false;
     int maxScore = -200;
+    int nCandidates = 10, nBest = 10;                   // :242-243
+    float minPctSimilarity = 0;                         // :299
+    float minFractionToBeConsideredOverlapping = 0.75f; // :212
     int tieBreak = GBA_TIE_DIAG_LEFT_UP;
     int sdpTupleSize = 11, sdpIns = 5, sdpDel = 10;     // :220-222
     uint32_t sdpMaxFragments = 1024;                    // not a BLASR option: the device's budget of maximal matches per candidate
@@ -43,6 +46,7 @@ struct AlignmentCandidate {
     uint32_t tAlignedSeqPos = 0, qAlignedSeqPos = 0, tAlignedSeqLength = 0, qAlignedSeqLength = 0;
     uint32_t qPos = 0, tPos = 0;
     std::vector<Block> blocks;
+    int tIndex = 0;                // contig of the window (compared at BlasrUtilsImpl.hpp:552)
     int score = 0;
     uint64_t nCells = 0;
     uint32_t nMatch = 0, nMismatch = 0, nIns = 0, nDel = 0;
@@ -593,7 +597,9 @@ inline int RefineLegacy(const std::string &read, std::vector<AlignmentCandidate 
         c.nBlocks = p.n_blk;
         c.qPos = p.q_pos; c.tPos = p.t_pos;
         StatsInto(c, p);
-        c.qStart = p.q_start; c.qEnd = p.q_end; c.tStart = p.t_start; c.tEnd = p.t_end; c.haveInterval = true;
+        // read- / window-absolute, as RefineBatch::Run reports them
+        c.qStart = c.qAlignedSeqPos + p.q_start; c.qEnd = c.qAlignedSeqPos + p.q_end;
+        c.tStart = c.tAlignedSeqPos + p.t_start; c.tEnd = c.tAlignedSeqPos + p.t_end; c.haveInterval = true;
     }
     return GBA_OK;
 }
@@ -614,17 +620,29 @@ inline int ExtendAlignments(const std::string &read, std::vector<AlignmentCandid
     struct Job { AlignmentCandidate *c; int side; uint64_t q0, t0, rl, gl; };
     std::vector<Job> jobs;
     KBandBatch batch(ctx);
+    // the prelude of :1020-1037, for every candidate: the aligned sequences are cut to the alignment's own boundaries
+    // (from the first block's start over QEnd() / TEnd() bases) and qPos / tPos become 0, so that what is spliced on
+    // below lands directly behind the last aligned base and in front of the first
+    for (AlignmentCandidate *c : alignmentPtrs) {
+        const uint32_t qend = c->blocks.empty() ? 0 : c->blocks.back().qPos + c->blocks.back().length;
+        const uint32_t tend = c->blocks.empty() ? 0 : c->blocks.back().tPos + c->blocks.back().length;
+        if ((uint64_t)c->qAlignedSeqPos + c->qPos + qend > read.size() || (uint64_t)c->tPos + tend > c->tAlignedSeq.size())
+            throw std::out_of_range("candidate alignment exceeds its sequences");
+        c->qAlignedSeqPos += c->qPos; c->qAlignedSeqLength = qend; c->qPos = 0;
+        c->qAlignedSeq = read.substr(c->qAlignedSeqPos, qend);
+        c->tAlignedSeqPos += c->tPos; c->tAlignedSeq = c->tAlignedSeq.substr(c->tPos, tend); c->tAlignedSeqLength = tend; c->tPos = 0;
+    }
     for (AlignmentCandidate *c : alignmentPtrs) {
         if (c->blocks.empty()) continue;
         const Block &last = c->blocks.back();
-        const uint64_t lastQ = (uint64_t)last.qPos + last.length + c->qPos + c->qAlignedSeqPos;
-        const uint64_t lastT = (uint64_t)last.tPos + last.length + c->tPos + c->tAlignedSeqPos;
+        const uint64_t lastQ = (uint64_t)last.qPos + last.length + c->qAlignedSeqPos;
+        const uint64_t lastT = (uint64_t)last.tPos + last.length + c->tAlignedSeqPos;
         if (lastQ < read.size() && lastT < contigEnd) {
             const uint64_t rl = std::min<uint64_t>(read.size() - lastQ, maximumExtendLength), gl = std::min<uint64_t>(contigEnd - lastT, maximumExtendLength);
             jobs.push_back(Job{c, 0, lastQ, lastT, rl, gl});
             batch.Add(read.data() + lastQ, rl, genome.data() + lastT, gl, extendBandSize, false);
         }
-        const uint64_t firstQ = (uint64_t)c->qPos + c->qAlignedSeqPos, firstT = (uint64_t)c->tPos + c->tAlignedSeqPos;
+        const uint64_t firstQ = c->qAlignedSeqPos, firstT = c->tAlignedSeqPos;
         if (firstQ > 0 && firstT > contigStart) {
             const uint64_t rl = std::min<uint64_t>(firstQ, maximumExtendLength), gl = std::min<uint64_t>(firstT - contigStart, maximumExtendLength);
             jobs.push_back(Job{c, 1, firstQ - rl, firstT - gl, rl, gl});
@@ -645,8 +663,8 @@ inline int ExtendAlignments(const std::string &read, std::vector<AlignmentCandid
             const gba_block *eb = &batch.blocks[p.blk_off];
             const uint64_t oq = (uint64_t)c.qPos + c.qAlignedSeqPos, ot = (uint64_t)c.tPos + c.tAlignedSeqPos;
             const uint64_t qend = p.q_pos + eb[p.n_blk - 1].q_pos + eb[p.n_blk - 1].length, tend = p.t_pos + eb[p.n_blk - 1].t_pos + eb[p.n_blk - 1].length;
-            const uint32_t qlen = c.qAlignedSeqLength ? c.qAlignedSeqLength : (uint32_t)c.qAlignedSeq.size();
-            if (j.side == 0) {
+            const uint32_t qlen = (uint32_t)c.qAlignedSeq.size();
+            if (j.side == 0) {                      // :1111-1119
                 for (uint32_t i = 0; i < p.n_blk; i++)
                     c.blocks.push_back(Block{(uint32_t)(j.q0 + p.q_pos + eb[i].q_pos - oq), (uint32_t)(j.t0 + p.t_pos + eb[i].t_pos - ot), eb[i].length});
                 c.tAlignedSeq.append(genome, j.t0, tend);
@@ -658,7 +676,8 @@ inline int ExtendAlignments(const std::string &read, std::vector<AlignmentCandid
                 const uint64_t nq = j.q0 + p.q_pos, nt = j.t0 + p.t_pos;                 // new origin of the blocks
                 for (const Block &b : c.blocks) nb.push_back(Block{(uint32_t)(b.qPos + oq - nq), (uint32_t)(b.tPos + ot - nt), b.length});
                 c.blocks.swap(nb);
-                c.tAlignedSeq = genome.substr(j.t0, j.gl - c.tPos) + c.tAlignedSeq;
+                // :1170: the WHOLE prefix goes in front (Append(tAlignedSeq, length - tPos) with tPos = 0 after the prelude)
+                c.tAlignedSeq = genome.substr(j.t0, j.gl) + c.tAlignedSeq;
                 c.tAlignedSeqPos = (uint32_t)j.t0; c.qAlignedSeqPos = (uint32_t)j.q0;
                 c.tPos = p.t_pos; c.qPos = p.q_pos;
                 c.qAlignedSeqLength = (uint32_t)j.rl + qlen;
@@ -670,8 +689,9 @@ inline int ExtendAlignments(const std::string &read, std::vector<AlignmentCandid
             c.score += p.score;
             const uint32_t cols = c.nMatch + c.nMismatch + c.nIns + c.nDel;
             c.pctSimilarity = cols ? 100.0f * c.nMatch / cols : 0.0f;
-            c.qStart = c.qPos + c.blocks.front().qPos; c.qEnd = c.qPos + c.blocks.back().qPos + c.blocks.back().length;
-            c.tStart = c.tPos + c.blocks.front().tPos; c.tEnd = c.tPos + c.blocks.back().tPos + c.blocks.back().length;
+            // read- / genome-absolute, as RefineBatch::Run reports them
+            c.qStart = c.qAlignedSeqPos + c.qPos + c.blocks.front().qPos; c.qEnd = c.qAlignedSeqPos + c.qPos + c.blocks.back().qPos + c.blocks.back().length;
+            c.tStart = c.tAlignedSeqPos + c.tPos + c.blocks.front().tPos; c.tEnd = c.tAlignedSeqPos + c.tPos + c.blocks.back().tPos + c.blocks.back().length;
             c.haveInterval = true;
             done++;
         }
@@ -697,6 +717,56 @@ inline int RefineAlignments(const std::string &read, std::vector<AlignmentCandid
         std::stable_sort(alignmentPtrs.begin(), alignmentPtrs.end(),
                          [](const AlignmentCandidate *a, const AlignmentCandidate *b) { return a->score < b->score; });
     return rc;
+}
+
+// Among the first nCandidates candidates, drop from the first one that has no blocks or scores above maxScore to the
+// end (:485-509), as MapRead does right after refining (iblasr/BlasrAlignImpl.hpp:381).  The vector holds borrowed
+// pointers here: nothing is deleted.
+inline size_t RemoveLowQualityAlignments(std::vector<AlignmentCandidate *> &alignmentPtrs, const MappingParameters &params)
+{
+    const size_t lim = std::min<size_t>((size_t)params.nCandidates, alignmentPtrs.size());
+    for (size_t i = 0; i < lim; i++) {
+        const AlignmentCandidate &c = *alignmentPtrs[i];
+        const bool empty = c.blocks.empty() && c.nBlocks == 0;
+        if (empty || c.score > params.maxScore) { alignmentPtrs.resize(i); break; }
+    }
+    return alignmentPtrs.size();
+}
+
+// GenomicTBegin() / GenomicTEnd() (libcpp's Alignment, not in the reference tree: UNPINNED): the stretch of the target
+// strand between the first aligned base and the end of the last block, tAlignedSeqPos + tPos (+ TEnd()).
+inline void GenomicTInterval(const AlignmentCandidate &c, int64_t &begin, int64_t &end)
+{
+    begin = end = (int64_t)c.tAlignedSeqPos + c.tPos;
+    if (!c.blocks.empty()) end = begin + c.blocks.back().tPos + c.blocks.back().length;
+    else if (c.haveInterval && c.nBlocks) { begin = c.tStart; end = c.tEnd; }
+}
+
+// RemoveOverlappingAlignments (:523-605; called at iblasr/BlasrAlignImpl.hpp:382): of two candidates on the same contig
+// whose target stretches contain one another, the contained one goes when its score is no better; a candidate below
+// minPctSimilarity is not used as the outer one; the survivors keep their order.  Borrowed pointers: nothing is deleted.
+inline size_t RemoveOverlappingAlignments(std::vector<AlignmentCandidate *> &alignmentPtrs, const MappingParameters &params)
+{
+    const size_t n = alignmentPtrs.size();
+    std::vector<unsigned char> contained(n, 0);
+    for (size_t i = 0; i + 1 < n; i++) {
+        const AlignmentCandidate &a = *alignmentPtrs[i];
+        if (a.pctSimilarity < params.minPctSimilarity) continue;
+        int64_t ab, ae;
+        GenomicTInterval(a, ab, ae);
+        for (size_t j = i + 1; j < n; j++) {
+            const AlignmentCandidate &b = *alignmentPtrs[j];
+            if (contained[j] || a.tIndex != b.tIndex) continue;
+            int64_t bb, be;
+            GenomicTInterval(b, bb, be);
+            if (ab <= bb && ae >= be) { if (a.score <= b.score) contained[j] = 1; }
+            else if (bb <= ab && be >= ae) { if (b.score <= a.score) contained[i] = 1; }
+        }
+    }
+    size_t keep = 0;
+    for (size_t i = 0; i < n; i++) if (!contained[i]) alignmentPtrs[keep++] = alignmentPtrs[i];
+    alignmentPtrs.resize(keep);
+    return keep;
 }
 
 // ---- mapping qualities of one read's candidates: StoreMapQVs (:108-309) and its helpers.
@@ -735,7 +805,7 @@ inline void StoreMapQVs(std::vector<AlignmentCandidate *> &alignmentPtrs, const 
                         bool scaleMapQVByNumSignificantClusters = false)
 {
     const size_t n = alignmentPtrs.size();
-    for (size_t i = 0; i < n; i++) alignmentPtrs[i]->probScore = -(float)rawProbScore[i] / 10.0f;
+    for (size_t i = 0; i < n; i++) alignmentPtrs[i]->probScore = (float)(-rawProbScore[i] / 10.0);
     std::vector<std::vector<int>> partitions;                        // PartitionOverlappingAlignments, :411-444
     for (size_t i = 0; i < n; i++) {
         bool found = false;
@@ -762,16 +832,17 @@ inline void StoreMapQVs(std::vector<AlignmentCandidate *> &alignmentPtrs, const 
             int s, e; GetQInterval(*alignmentPtrs[i], s, e);
             int mm = 0;
             if (s - begin > kMapQVEndAlignWiggle || end - e > kMapQVEndAlignWiggle) mm = 15 * ((s - begin) + (end - e));
-            alignmentPtrs[i]->probScore += -(float)mm * 0.5f;
+            alignmentPtrs[i]->probScore = (float)(alignmentPtrs[i]->probScore + -(mm) * 0.5);
         }
-        double denom = alignmentPtrs[part[0]]->probScore;
-        for (size_t k = 1; k < part.size(); k++) denom = LogSumOfTwo(denom, alignmentPtrs[part[k]]->probScore);
+        float denom = alignmentPtrs[part[0]]->probScore;             // `float mapQVDenominator`, :238
+        for (size_t k = 1; k < part.size(); k++) denom = (float)LogSumOfTwo(denom, alignmentPtrs[part[k]]->probScore);
         for (int i : part) {
             AlignmentCandidate &c = *alignmentPtrs[i];
             if (part.size() == 1) c.mapQV = kMaxPhredScore;
             else if (c.probScore - denom < -20) c.mapQV = 0;
             else {
-                const double expo = std::exp(std::log(10.0) * (c.probScore - denom)), diff = 1.0 - expo;
+                const double sub = c.probScore - denom;              // float - float, then `double sub`, :278
+                const double expo = std::exp(std::log(10.0) * sub), diff = 1.0 - expo;
                 int q = expo == 0 ? 0 : diff == 0 ? kMaxPhredScore : Phred(diff);
                 c.mapQV = q > kMaxPhredScore ? kMaxPhredScore : q;
             }

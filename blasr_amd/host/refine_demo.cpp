@@ -13,11 +13,16 @@
 //   qv       every candidate line carries five more strings behind its blocks (insertionQV deletionQV deletionTag substitutionQV
 //            substitutionTag, quality values as letters: value + 33): the batch runs with the IDS scorer's costs (IdsProfile)
 //   legacy   run the branch without guided alignment (RefineLegacy: AffineKBandAlign in a band around the guide's drift)
-//   extend   stdin is n, the genome, then per candidate "read tAlignedSeqPos qAlignedSeqPos nblk blocks..." (its window is the
-//            genome from tAlignedSeqPos over the span of its blocks): the -extend step (ExtendAlignments); prints per candidate
-//            status score qAlignedSeqPos tAlignedSeqPos qPos tPos nblk blocks...
+//   extend   stdin is n, the genome, then per candidate "read tAlignedSeqPos windowLength qAlignedSeqPos qPos tPos nblk blocks..."
+//            (its window is the genome from tAlignedSeqPos over windowLength bases, the blocks are relative to qPos / tPos):
+//            the -extend step (ExtendAlignments); prints per candidate
+//            status score qAlignedSeqPos tAlignedSeqPos qPos tPos qStart qEnd tStart tEnd tAlignedSeq nblk blocks...
 //   mapqv    no GPU: stdin is n, then "qStart qEnd rawProbScore" per candidate of ONE read; prints their mapQVs
+//   filters  no GPU: stdin is n, then "tIndex tBegin tEnd score pctSimilarity nBlocks" per candidate of ONE read, in order;
+//            runs RemoveLowQualityAlignments, then RemoveOverlappingAlignments (iblasr/BlasrAlignImpl.hpp:381-382) and
+//            prints the input indices of the survivors
 #include <cstdio>
+#include <cstdlib>
 #include <iostream>
 
 #include "gba_refine.hpp"
@@ -45,20 +50,39 @@ int main(int argc, char **argv)
         std::printf("\n");
         return 0;
     }
+    if (mode == "filters") {
+        std::vector<gba::AlignmentCandidate> cs(n);
+        std::vector<gba::AlignmentCandidate *> ptrs;
+        for (size_t i = 0; i < n; i++) {
+            uint32_t t0, t1, nb;
+            std::cin >> cs[i].tIndex >> t0 >> t1 >> cs[i].score >> cs[i].pctSimilarity >> nb;
+            cs[i].tAlignedSeqPos = t0;
+            if (nb) cs[i].blocks.push_back(gba::Block{0, 0, t1 - t0});
+            ptrs.push_back(&cs[i]);
+        }
+        gba::MappingParameters params;
+        if (argc > 2) params.minPctSimilarity = (float)atof(argv[2]);
+        if (argc > 3) params.nCandidates = atoi(argv[3]);
+        gba::RemoveLowQualityAlignments(ptrs, params);
+        gba::RemoveOverlappingAlignments(ptrs, params);
+        for (auto *c : ptrs) std::printf("%d ", (int)(c - cs.data()));
+        std::printf("\n");
+        return 0;
+    }
     if (mode == "extend") {
         std::string genome;
         std::cin >> genome;
         std::vector<std::string> rd(n);
         std::vector<gba::AlignmentCandidate> cs(n);
         for (size_t i = 0; i < n; i++) {
-            size_t nb;
-            std::cin >> rd[i] >> cs[i].tAlignedSeqPos >> cs[i].qAlignedSeqPos >> nb;
+            size_t nb, wl;
+            std::cin >> rd[i] >> cs[i].tAlignedSeqPos >> wl >> cs[i].qAlignedSeqPos >> cs[i].qPos >> cs[i].tPos >> nb;
             cs[i].blocks.resize(nb);
             for (auto &b : cs[i].blocks) std::cin >> b.qPos >> b.tPos >> b.length;
-            const gba::Block &l = cs[i].blocks.back();
-            cs[i].tAlignedSeq = genome.substr(cs[i].tAlignedSeqPos, l.tPos + l.length);
-            cs[i].qAlignedSeqLength = l.qPos + l.length;
-            cs[i].qAlignedSeq = rd[i].substr(cs[i].qAlignedSeqPos, cs[i].qAlignedSeqLength);
+            cs[i].tAlignedSeq = genome.substr(cs[i].tAlignedSeqPos, wl);
+            cs[i].tAlignedSeqLength = (uint32_t)wl;
+            cs[i].qAlignedSeqLength = (uint32_t)(rd[i].size() - cs[i].qAlignedSeqPos);
+            cs[i].qAlignedSeq = rd[i].substr(cs[i].qAlignedSeqPos);
         }
         gba_ctx *ctx = nullptr;
         gba_config cfg{0, 0, nullptr};
@@ -71,7 +95,8 @@ int main(int argc, char **argv)
         }
         if (rc != GBA_OK) { std::fprintf(stderr, "ExtendAlignments: %s\n", gba_strerror(rc)); return 1; }
         for (auto &c : cs) {
-            std::printf("%d %d %u %u %u %u %zu", c.status, c.score, c.qAlignedSeqPos, c.tAlignedSeqPos, c.qPos, c.tPos, c.blocks.size());
+            std::printf("%d %d %u %u %u %u %u %u %u %u %s %zu", c.status, c.score, c.qAlignedSeqPos, c.tAlignedSeqPos, c.qPos, c.tPos,
+                        c.qStart, c.qEnd, c.tStart, c.tEnd, c.tAlignedSeq.c_str(), c.blocks.size());
             for (auto &b : c.blocks) std::printf(" %u %u %u", b.qPos, b.tPos, b.length);
             std::printf("\n");
         }

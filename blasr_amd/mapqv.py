@@ -15,6 +15,13 @@ powers of ten) and Phred (-10 log10, truncated to an integer).
 import math
 from typing import List, Sequence
 
+import numpy as np
+
+# probScore is a float field of the candidate and the denominator a `float mapQVDenominator` (:238): sums and
+# differences are rounded to single precision where the reference stores or subtracts them, the exponentials run
+# in double (`double sub ... exp(log10*sub)`, :277-280).  Phred() truncates, so the rounding can move a boundary case by one.
+_f32 = np.float32
+
 MAX_PHRED_SCORE = 254            # iblasr/BlasrHeaders.h:19
 MAPQV_END_ALIGN_WIGGLE = 5       # iblasr/BlasrHeaders.h:20
 
@@ -95,7 +102,7 @@ def store_map_qvs(cands: Sequence, raw_prob_scores: Sequence[int], min_fraction_
     probScore = -raw / 10 (:145-149).  min_fraction_overlapping is
     params.minFractionToBeConsideredOverlapping, n_candidates params.nCandidates."""
     for c, raw in zip(cands, raw_prob_scores):
-        c.probScore = -float(raw) / 10.0
+        c.probScore = float(_f32(-float(raw) / 10.0))
     parts = partition_overlapping_alignments(cands, min_fraction_overlapping)
     for part in parts:
         # the widest aligned stretch of the partition (:170-191)
@@ -110,18 +117,19 @@ def store_map_qvs(cands: Sequence, raw_prob_scores: Sequence[int], min_fraction_
             mm = 0
             if s - begin > MAPQV_END_ALIGN_WIGGLE or end - e > MAPQV_END_ALIGN_WIGGLE:
                 mm = sum_mismatches(cands[i], 15, begin, end)
-            cands[i].probScore += -mm * 0.5
+            cands[i].probScore = float(_f32(cands[i].probScore + -mm * 0.5))
         denom = cands[part[0]].probScore
         for i in part[1:]:
-            denom = log_sum_of_two(denom, cands[i].probScore)
+            denom = float(_f32(log_sum_of_two(denom, cands[i].probScore)))
         for i in part:
             c = cands[i]
+            sub = float(_f32(c.probScore) - _f32(denom))       # float - float
             if len(part) == 1:
                 c.mapQV = MAX_PHRED_SCORE                       # :266-268
-            elif c.probScore - denom < -20:
+            elif sub < -20:
                 c.mapQV = 0                                     # :273-275
             else:
-                expo = math.exp(math.log(10) * (c.probScore - denom))
+                expo = math.exp(math.log(10) * sub)
                 diff = 1.0 - expo
                 if expo == 0:
                     q = 0

@@ -36,6 +36,10 @@ class MappingParameters:
     refineAlignments: bool = True
     sortRefinedAlignments: bool = True
     maxScore: int = -200
+    nCandidates: int = 10    # :243
+    nBest: int = 10          # :242
+    minPctSimilarity: float = 0.0   # :299
+    minFractionToBeConsideredOverlapping: float = 0.75   # :212
     maxBandSize: int = 250   # libcpp's MAX_BAND_SIZE (ctest/concordant.t:23 mentions it)
     tieBreak: int = _lib.TIE_DIAG_LEFT_UP
     sdpTupleSize: int = 11   # :222
@@ -57,6 +61,7 @@ class AlignmentCandidate:
     tPos: int = 0
     blocks: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=BLOCK_DT))
     tStrand: int = 0
+    tIndex: int = 0                         # index of the contig the window lies in (seqdb), compared at BlasrUtilsImpl.hpp:552
     score: int = 0
     nCells: int = 0
     nMatch: int = 0
@@ -413,13 +418,55 @@ def refine_global(read: bytes, cands: List[AlignmentCandidate], params: MappingP
 
 
 def RemoveLowQualityAlignments(cands: List[AlignmentCandidate], params: MappingParameters):
-    """Drop from the first candidate that has no blocks or scores above maxScore
-    (iblasr/BlasrUtilsImpl.hpp:485-509), as MapRead does right after refining."""
-    for i, c in enumerate(cands):
+    """Among the first nCandidates candidates, drop from the first one that has no blocks or scores above
+    maxScore to the end (iblasr/BlasrUtilsImpl.hpp:485-509), as MapRead does right after refining."""
+    for i in range(min(params.nCandidates, len(cands))):
+        c = cands[i]
         if c.n_blocks() == 0 or c.score > params.maxScore:
             del cands[i:]
             break
     return cands
+
+
+def genomic_t_interval(c: AlignmentCandidate):
+    """GenomicTBegin() / GenomicTEnd() of a candidate (libcpp's Alignment, not in the reference tree: UNPINNED): the
+    stretch of its target strand between the first aligned base and the end of the last block,
+    tAlignedSeqPos + tPos (+ TEnd())."""
+    if c.n_blocks() == 0:
+        b = c.tAlignedSeqPos + c.tPos
+        return b, b
+    if len(c.blocks) == 0:                      # refined without a block arena: the interval came with the pair result
+        return c.tInterval
+    last = c.blocks[len(c.blocks) - 1]
+    b = c.tAlignedSeqPos + c.tPos
+    return b, b + int(last["t_pos"]) + int(last["length"])
+
+
+def RemoveOverlappingAlignments(cands: List[AlignmentCandidate], params: MappingParameters):
+    """RemoveOverlappingAlignments (iblasr/BlasrUtilsImpl.hpp:523-605), what MapRead runs after the refine and the
+    quality filter (iblasr/BlasrAlignImpl.hpp:382): of two candidates on the same contig whose target stretches
+    contain one another, the contained one goes when its score is no better (j inside i and score_i <= score_j drops
+    j; i inside j and score_j <= score_i drops i); a candidate below minPctSimilarity is not used as the outer one;
+    the survivors keep their order.  Returns the number left."""
+    n = len(cands)
+    contained = [False] * n
+    for i in range(max(n - 1, 0)):
+        a = cands[i]
+        if a.pctSimilarity < params.minPctSimilarity:
+            continue
+        ab, ae = genomic_t_interval(a)
+        for j in range(i + 1, n):
+            if contained[j] or a.tIndex != cands[j].tIndex:
+                continue
+            bb, be = genomic_t_interval(cands[j])
+            if ab <= bb and ae >= be:
+                if a.score <= cands[j].score:
+                    contained[j] = True
+            elif bb <= ab and be >= ae:
+                if cands[j].score <= a.score:
+                    contained[i] = True
+    cands[:] = [c for c, gone in zip(cands, contained) if not gone]
+    return len(cands)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -676,19 +723,34 @@ def ExtendAlignments(read: bytes, cands: List[AlignmentCandidate], genome: bytes
     Counts and score of the pieces add up (ComputeAlignmentStats with distScoreFn2 at :1214 rescans
     the whole alignment; with its linear gap costs that is the sum).  Returns the number of ends extended."""
     contigEnd = len(genome) if contigEnd is None else contigEnd
+    # The prelude of :1020-1037, for every candidate: the aligned sequences are cut to the alignment's own
+    # boundaries (from the first block's start over QEnd() / TEnd() bases) and qPos / tPos become 0, so that
+    # what is spliced on below lands directly behind the last aligned base and in front of the first.
+    for c in cands:
+        nb = len(c.blocks)
+        qend = int(c.blocks[nb - 1]["q_pos"]) + int(c.blocks[nb - 1]["length"]) if nb else 0
+        tend = int(c.blocks[nb - 1]["t_pos"]) + int(c.blocks[nb - 1]["length"]) if nb else 0
+        c.qAlignedSeqPos += c.qPos
+        c.qAlignedSeqLength = qend
+        c.qAlignedSeq = read[c.qAlignedSeqPos:c.qAlignedSeqPos + qend]
+        c.qPos = 0
+        c.tAlignedSeqPos += c.tPos
+        c.tAlignedSeq = c.tAlignedSeq[c.tPos:c.tPos + tend]
+        c.tAlignedSeqLength = tend
+        c.tPos = 0
     jobs, seqs, rev = [], [], []
     for ci, c in enumerate(cands):
         if len(c.blocks) == 0:
             continue
         last = c.blocks[len(c.blocks) - 1]
-        lastQ = int(last["q_pos"]) + int(last["length"]) + c.qPos + c.qAlignedSeqPos
-        lastT = int(last["t_pos"]) + int(last["length"]) + c.tPos + c.tAlignedSeqPos
+        lastQ = int(last["q_pos"]) + int(last["length"]) + c.qAlignedSeqPos
+        lastT = int(last["t_pos"]) + int(last["length"]) + c.tAlignedSeqPos
         rl = min(len(read) - lastQ, MAXIMUM_EXTEND_LENGTH)
         gl = min(contigEnd - lastT, MAXIMUM_EXTEND_LENGTH)
         if rl > 0 and gl > 0:
             jobs.append((ci, 0, lastQ, lastT, rl, gl)); rev.append(0)
             seqs.append((read[lastQ:lastQ + rl], _genome_slice(genome, lastT, gl, c.tStrand)))
-        firstQ, firstT = c.qPos + c.qAlignedSeqPos, c.tPos + c.tAlignedSeqPos
+        firstQ, firstT = c.qAlignedSeqPos, c.tAlignedSeqPos
         rl = min(firstQ, MAXIMUM_EXTEND_LENGTH)
         gl = min(firstT - contigStart, MAXIMUM_EXTEND_LENGTH)
         if rl > 0 and gl > 0:
@@ -711,19 +773,22 @@ def ExtendAlignments(read: bytes, cands: List[AlignmentCandidate], genome: bytes
             qend, tend = eq + int(eb[-1]["q_pos"]) + int(eb[-1]["length"]), et + int(eb[-1]["t_pos"]) + int(eb[-1]["length"])
             oq, ot = c.qPos + c.qAlignedSeqPos, c.tPos + c.tAlignedSeqPos      # origin of the candidate's blocks
             if side == 0:
+                # :1111-1119: the genome suffix up to the extension's end goes behind tAlignedSeq, the query grows by as much
                 nb = eb.copy()
                 nb["q_pos"] += np.uint32(q0 + eq - oq); nb["t_pos"] += np.uint32(t0 + et - ot)
                 c.blocks = np.concatenate([c.blocks, nb])
                 c.tAlignedSeq = c.tAlignedSeq + ts[:tend]
-                c.qAlignedSeqLength = (c.qAlignedSeqLength or len(c.qAlignedSeq)) + qend
+                c.qAlignedSeqLength = len(c.qAlignedSeq) + qend
                 c.qAlignedSeq = read[c.qAlignedSeqPos:c.qAlignedSeqPos + c.qAlignedSeqLength]
                 c.tAlignedSeqLength = len(c.tAlignedSeq)
             else:
+                # :1166-1183: the WHOLE genome prefix goes in front (genomePrefix.Append(tAlignedSeq, length - tPos) with
+                # tPos = 0 after the prelude), the extension's own tPos / qPos say where in it the alignment starts
                 ob = c.blocks.copy()
                 ob["q_pos"] += np.uint32(oq - (q0 + eq)); ob["t_pos"] += np.uint32(ot - (t0 + et))
                 c.blocks = np.concatenate([eb, ob])
-                c.tAlignedSeq = ts[:gl - c.tPos] + c.tAlignedSeq
-                old_qlen = c.qAlignedSeqLength or len(c.qAlignedSeq)
+                c.tAlignedSeq = ts + c.tAlignedSeq
+                old_qlen = len(c.qAlignedSeq)
                 c.tAlignedSeqPos, c.qAlignedSeqPos = t0, q0
                 c.tPos, c.qPos = et, eq
                 c.qAlignedSeqLength = rl + old_qlen

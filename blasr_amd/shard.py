@@ -8,10 +8,11 @@ need nothing from another GPU), and the results are merged on the host in input 
 output does not depend on the number of GPUs.  There is no collective on the data path.
 
 Two forms:
-  MultiGpuRefiner   one process, one context per GPU: the replacement of the reference's pool of
-                    -nproc worker threads (Blasr.cpp:1457-1488).  One caller hands over one batch;
-                    every GPU gets its reads through the asynchronous gba_submit, all run at the
-                    same time, the results come back as one array in input order.
+  MultiGpuRefiner   one process, one pipeline of contexts per GPU: the replacement of the reference's
+                    pool of -nproc worker threads (Blasr.cpp:1457-1488).  One caller hands over one
+                    batch; GPU g gets a CONTIGUOUS range of its reads (cut at read boundaries, balanced by
+                    query bases), so it stages and holds only its own share of the arenas, and the results
+                    in input order are the GPUs' result arrays one after the other: nothing is gathered.
   SharedMerge       one process per GPU (torch.distributed launch): every rank writes the results
                     of its reads into one node-wide, preallocated array at the reads' own places.
 """
@@ -76,48 +77,201 @@ def merge_in_input_order(n: int, parts: Sequence):
     return pairs, blocks
 
 
-class MultiGpuRefiner:
-    """One caller, several GPUs, one batch, results in input order."""
+def contiguous_ranges(batch, world: int) -> List[tuple]:
+    """(lo, hi) pair ranges, one per rank, that tile the batch in order: cut only between reads
+    (batch["read_id"]; every pair its own read without it) and balanced by query bases, the
+    predictor of a pair's DP cells (rows x band)."""
+    n = int(batch["n_pairs"])
+    if n == 0:
+        return [(0, 0)] * world
+    rid = np.asarray(batch["read_id"]) if batch.get("read_id") is not None else np.arange(n)
+    cost = np.cumsum(np.asarray(batch["q_len"], np.int64))
+    starts = np.flatnonzero(np.concatenate(([True], rid[1:] != rid[:-1])))        # first pair of every read
+    before = np.concatenate(([0], cost))[starts]                                   # cost in front of each read
+    cuts, k_prev, R = [0], 0, len(starts)
+    for r in range(1, world):
+        want = cost[-1] * r / world
+        k = int(np.searchsorted(before, want, side="left"))          # the read boundary nearest to the rank's share
+        if 0 < k < R and want - before[k - 1] < before[k] - want:
+            k -= 1
+        if R >= world:                                  # every rank gets a read when there are enough of them
+            k = min(max(k, k_prev + 1), R - (world - r))
+        k = max(k, k_prev)
+        cuts.append(int(starts[k]) if k < R else n)
+        k_prev = k
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
-    def __init__(self, devices: Sequence[int]):
-        from .api import Context
-        self.ctxs = [Context(d) for d in devices]
+
+_ARENAS = (("q_arena", "q_off", "q_len", 1), ("t_arena", "t_off", "t_len", 1), ("blocks", "blk_off", "n_blk", 1))
+
+
+def range_batch(batch, lo: int, hi: int):
+    """Pairs [lo, hi) of a batch as a batch of their own whose arenas are the stretches those pairs point
+    into (views, nothing is copied but the three offset arrays, which are rebased): what one GPU of
+    several stages, holds and is told the extent of.  Returns (sub-batch, bytes of the three stretches)."""
+    out = {"n_pairs": hi - lo}
+    for k, v in batch.items():
+        if k in PER_PAIR and v is not None:
+            out[k] = np.asarray(v)[lo:hi]
+        elif k != "n_pairs":
+            out[k] = v
+    staged = 0
+    packed = bool(batch.get("q_packed"))
+    for arena, off, length, _ in _ARENAS:
+        a = batch.get(arena)
+        if a is None or hi == lo:
+            continue
+        o = np.asarray(batch[off][lo:hi], np.int64); l = np.asarray(batch[length][lo:hi], np.int64)
+        live = l > 0
+        if not live.any():
+            continue
+        first, last = int(o[live].min()), int((o[live] + l[live]).max())
+        if arena == "q_arena" and packed:
+            first -= first % 16                         # packed reads move 16 bases (4 bytes) at a time
+            out[arena] = np.asarray(a)[first // 4:(last + 15) // 16 * 4]
+            out["q_bases"] = last - first
+        else:
+            out[arena] = np.asarray(a)[first:last]
+        out[off] = (np.asarray(batch[off][lo:hi], np.uint64) - np.uint64(first)).astype(np.uint64)
+        if arena == "q_arena" and batch.get("q_profile") is not None:
+            out["q_profile"] = np.asarray(batch["q_profile"])[first * 11:last * 11]
+        staged += out[arena].nbytes
+    return out, staged
+
+
+class Segments:
+    """The results of one batch as the GPUs left them: segment g = (lo, hi, pairs, blocks, blocks_needed)
+    for the pairs [lo, hi) of the batch; pairs[k]["blk_off"] indexes the segment's own block array.
+    Segments tile the batch in order, so reading them one after the other is reading the batch in
+    input order; merged() copies them into the two arrays a single context would have returned."""
+
+    def __init__(self, n, segs, rc):
+        self.n, self.segs, self.rc = n, segs, rc
+
+    def __iter__(self):
+        return iter(self.segs)
+
+    def pair(self, p):
+        """(pair result, its blocks) of input pair p."""
+        for lo, hi, pairs, blocks, _ in self.segs:
+            if lo <= p < hi:
+                r = pairs[p - lo]
+                return r, (blocks[int(r["blk_off"]):int(r["blk_off"]) + int(r["n_blk"])] if blocks is not None and int(r["status"]) == 0 else None)
+        raise IndexError(p)
+
+    def merged(self):
+        """(pairs, blocks) of the whole batch, blocks packed in input order, every blk_off rewritten:
+        two sequential copies and one prefix per GPU added to its pairs' offsets."""
+        pairs = np.concatenate([s[2] for s in self.segs]) if self.segs else np.zeros(0, _lib.PAIR_RESULT_DT)
+        want = all(s[3] is not None for s in self.segs)
+        blocks = np.concatenate([s[3][:s[4]] for s in self.segs]) if want and self.segs else np.zeros(0, _lib.BLOCK_DT)
+        base = 0
+        for lo, hi, _, _, needed in self.segs:
+            pairs["blk_off"][lo:hi] += np.uint64(base)
+            base += needed
+        return pairs, blocks
+
+
+class MultiGpuRefiner:
+    """One caller, several GPUs, one batch after the other, results in input order.
+
+    devices: the GPUs (a GPU may be named more than once: each entry is a worker of its own).  depth: contexts
+    per entry, used in turn (api.HostPipeline): with 2, batch k + 1 can be submitted while batch k runs, its
+    inputs travel under batch k's kernels.  Result buffers are page-locked memory of the context that fills
+    them, kept and reused from batch to batch; the block arena of a GPU is sized from what its last batch
+    needed (a first batch: a block per four query bases) and a batch that outgrows it is run again with the
+    size it reported."""
+
+    def __init__(self, devices: Sequence[int], depth: int = 1, stagger: float = 0.4):
+        from .api import HostPipeline
+        self.pipes = [HostPipeline(d, depth=depth, stagger=stagger) for d in devices]
+        self.depth = depth
+        self._bufs = [[{} for _ in range(depth)] for _ in devices]       # per worker and slot: pinned result buffers
+        self._flight = []                                                # tickets, oldest first
+        self._sub = 0
+        self._last_needed = [0] * len(devices)
+        self.bytes_staged = [0] * len(devices)                           # arena bytes of the last batch, per worker
+
+    @property
+    def ctxs(self):
+        return [c for p in self.pipes for c in p.ctxs]
 
     def close(self):
-        for c in self.ctxs:
-            c.close()
+        for p in self.pipes:
+            p.close()
 
     def set_scoring(self, scoring):
-        for c in self.ctxs:
-            c.set_scoring(scoring)
+        for p in self.pipes:
+            p.set_scoring(scoring)
 
     def set_reference(self, ref):
-        for c in self.ctxs:
-            c.set_reference(ref)
+        for p in self.pipes:
+            p.set_reference(ref)
 
     def set_guide_producer(self, params):
         """Batches without "blocks" get their guides on the GPU that refines them (Context.set_guide_producer)."""
-        for c in self.ctxs:
-            c.set_guide_producer(params)
+        for p in self.pipes:
+            p.set_guide_producer(params)
+
+    def _buffer(self, g, slot, name, count, dtype):
+        have = self._bufs[g][slot].get(name)
+        if have is None or len(have) < count:
+            have = self.pipes[g].ctxs[slot].host_array(max(count, 1) + count // 8, dtype)
+            self._bufs[g][slot][name] = have
+        return have[:count]
+
+    def _submit_range(self, g, slot, sub, want_blocks, cap):
+        n = int(sub["n_pairs"])
+        pairs = self._buffer(g, slot, "pairs", n, _lib.PAIR_RESULT_DT)
+        blocks = self._buffer(g, slot, "blocks", cap, _lib.BLOCK_DT) if want_blocks else None
+        self.pipes[g].submit(sub, pairs, blocks)
+        return pairs, blocks
+
+    def submit(self, batch, want_blocks: bool = True):
+        """Starts the batch on every GPU (gba_submit does not block) and returns; wait() collects it."""
+        if len(self._flight) >= self.depth:
+            raise _lib.GbaError(_lib.E_STATE)
+        slot = self._sub % self.depth
+        parts = []
+        for g, (lo, hi) in enumerate(contiguous_ranges(batch, len(self.pipes))):
+            sub, staged = range_batch(batch, lo, hi)
+            self.bytes_staged[g] = staged
+            qsum = int(np.asarray(sub["q_len"], np.int64).sum()) if hi > lo else 0
+            cap = self._last_needed[g] + self._last_needed[g] // 8 + 64 if self._last_needed[g] else qsum // 4 + (hi - lo) + 64
+            pairs, blocks = self._submit_range(g, slot, sub, want_blocks, cap) if hi > lo else (np.zeros(0, _lib.PAIR_RESULT_DT), None)
+            parts.append([lo, hi, sub, pairs, blocks, slot])
+        self._flight.append((int(batch["n_pairs"]), parts, want_blocks))
+        self._sub += 1
+
+    def wait(self) -> Segments:
+        """Blocks until the oldest submitted batch is complete on every GPU."""
+        if not self._flight:
+            raise _lib.GbaError(_lib.E_STATE)
+        n, parts, want_blocks = self._flight.pop(0)
+        segs, rc_all = [], 0
+        for g, (lo, hi, sub, pairs, blocks, slot) in enumerate(parts):
+            if hi == lo:
+                segs.append((lo, hi, pairs, blocks if want_blocks else None, 0))
+                continue
+            rc, needed = self.pipes[g].wait()
+            if rc == _lib.E_NOSPACE and want_blocks:         # the arena guessed from the last batch was too small: once more, at size
+                pairs, blocks = self._submit_range(g, slot, sub, True, needed + 64)
+                rc, needed = self.pipes[g].wait()
+            self._last_needed[g] = needed
+            rc_all = rc_all or rc
+            segs.append((lo, hi, pairs, blocks, needed))
+        return Segments(n, segs, rc_all)
+
+    def refine_host_segments(self, batch, want_blocks: bool = True) -> Segments:
+        self.submit(batch, want_blocks)
+        return self.wait()
 
     def refine_host(self, batch):
-        """Returns (pairs, blocks, rc) like Context.refine_host, for the whole batch."""
-        n = int(batch["n_pairs"])
-        idxs = split_by_read(batch, len(self.ctxs))
-        flight = []
-        for c, idx in zip(self.ctxs, idxs):           # every GPU starts at once: gba_submit does not block
-            sb = sub_batch(batch, idx)
-            cap = int(np.asarray(sb["q_len"]).astype(np.int64).sum()) + len(idx)
-            pairs = np.zeros(len(idx), dtype=_lib.PAIR_RESULT_DT)
-            blocks = np.zeros(cap, dtype=_lib.BLOCK_DT)
-            c.submit_host(sb, pairs, blocks)
-            flight.append((idx, pairs, blocks))
-        rc = 0
-        for c in self.ctxs:
-            r, _ = c.wait_host()
-            rc = rc or r
-        mp, mb = merge_in_input_order(n, flight)
-        return mp, mb, rc
+        """Returns (pairs, blocks, rc) like Context.refine_host, for the whole batch (Segments.merged())."""
+        s = self.refine_host_segments(batch)
+        mp, mb = s.merged()
+        return mp, mb, s.rc
 
 
 class SharedMerge:

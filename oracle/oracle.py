@@ -12,6 +12,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
+# GBA_ORACLE_SO: another build of the same sources (the sanitizer build `make -C oracle asan`, tests/test_oracle_asan.py)
+_ALT = os.environ.get("GBA_ORACLE_SO")
 
 MODE_LINEAR, MODE_AFFINE, MODE_KBAND = 0, 1, 2
 OK, EMPTY_GUIDE, BAD_GUIDE, UNREACHABLE, NOSPACE, END_OUT_OF_BAND = range(6)
@@ -52,7 +54,7 @@ RESULT_DT = np.dtype([
 
 def build(force=False):
     if force or not os.path.exists(_SO) or \
-            os.path.getmtime(_SO) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("gba_oracle.c", "sdp_oracle.c", "kband_oracle.c")):
+            os.path.getmtime(_SO) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("gba_oracle.c", "sdp_oracle.c", "kband_oracle.c", "cigar_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -63,9 +65,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
+        if _ALT is None and not os.path.exists(_SO):
             build()
-        _lib = C.CDLL(_SO)
+        _lib = C.CDLL(_ALT or _SO)
         _lib.gbo_align.restype = C.c_int
         _lib.gbo_align_qv.restype = C.c_int
         _lib.gbo_guide_rows.restype = C.c_int
@@ -76,6 +78,7 @@ def lib():
         _lib.kbo_full_dp.restype = C.c_int
         _lib.sdo_chain.restype = C.c_int
         _lib.sdo_chain_batch.restype = C.c_int
+        _lib.cgo_cigar.restype = C.c_int
     return _lib
 
 
@@ -317,3 +320,21 @@ def align_qv(q, t, blocks, params, profile, blk_cap=None):
                        out.ctypes.data_as(C.c_void_p), C.c_uint32(cap), C.byref(res))
     d = {f[0]: getattr(res, f[0]) for f in Result._fields_}
     return d, out[:min(d["n_blk"], cap)].copy()
+
+
+CIGAR_LETTERS = "MIDNSHP=X"
+
+
+def cigar_ops(blocks, q, t, q_pos=0, t_pos=0, use_seq_match=True, allow_adjacent_indels=False):
+    """cgo_cigar (cigar_oracle.c): the CIGAR of the alignment `blocks` (relative to q_pos / t_pos inside q / t) as a list
+    of (count, letter); bases are compared by code (case folded, everything outside ACGT is N)."""
+    b = _blocks(blocks)
+    qa, ta = _u8(q), _u8(t)
+    cap = 2 * (len(qa) + len(ta)) + 4
+    ops = np.zeros(cap, np.uint32)
+    flags = (1 if use_seq_match else 0) | (2 if allow_adjacent_indels else 0)
+    n = lib().cgo_cigar(qa.ctypes.data_as(C.c_void_p), ta.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.c_int(len(b)),
+                        C.c_uint32(int(q_pos)), C.c_uint32(int(t_pos)), C.c_uint32(flags), ops.ctypes.data_as(C.c_void_p), C.c_int(cap))
+    if n < 0:
+        raise ValueError("blocks overlap or are not increasing")
+    return [(int(w) >> 4, CIGAR_LETTERS[int(w) & 15]) for w in ops[:n]]

@@ -105,7 +105,32 @@ def test_cigar_agrees_with_the_path_statistics(oracle, synth):
         # M form: one op per aligned stretch
         plain = emit.cigar_ops(b, q, t, q_pos=qp, t_pos=tp, use_seq_match=False)
         assert sum(n for n, op in plain if op == "M") == mtot["="] + mtot["X"]
+        # the column-by-column restatement under oracle/ gives the same operations in all four forms
+        for sm in (True, False):
+            for adj in (True, False):
+                assert oracle.cigar_ops(b, q, t, qp, tp, use_seq_match=sm, allow_adjacent_indels=adj) == \
+                    emit.cigar_ops(b, q, t, q_pos=qp, t_pos=tp, use_seq_match=sm, allow_adjacent_indels=adj), (p, sm, adj)
     assert seen_adjacent > 0        # the workload does exercise the merge
+
+
+def test_cigar_oracle_hand_cases(oracle):
+    """oracle/cigar_oracle.c on cases small enough to check by eye (the same strings test_hand_cases expects of emit)."""
+    text = lambda ops: "".join("%d%s" % o for o in ops)
+    q, t = b"ACGTACGTAC", b"ACGTTCGTAC"
+    assert text(oracle.cigar_ops([(0, 0, 10)], q, t)) == "4=1X5="
+    assert text(oracle.cigar_ops([(0, 0, 10)], q, t, use_seq_match=False)) == "10M"
+    q2, t2 = b"AAAACCGGGGTTTT", b"AAAAGGGGATTTT"
+    assert text(oracle.cigar_ops([(0, 0, 4), (6, 4, 4), (10, 9, 4)], q2, t2)) == "4=2I4=1D4="
+    q3, t3 = b"AAAACTGGGG", b"AAAAGGGGG"
+    blk3 = [(0, 0, 4), (6, 5, 4)]
+    assert text(oracle.cigar_ops(blk3, q3, t3, allow_adjacent_indels=True)) == "4=2I1D4="
+    assert text(oracle.cigar_ops(blk3, q3, t3)) == "4=1X1I4="
+    assert text(oracle.cigar_ops(blk3, q3, t3, use_seq_match=False)) == "5M1I4M"
+    assert text(oracle.cigar_ops([(0, 0, 4)], b"NN" + q, b"N" + t, 2, 1)) == "4="
+    assert text(oracle.cigar_ops([(0, 0, 3)], b"acn", b"ACR")) == "3="             # case folded, letters outside ACGT are N
+    assert oracle.cigar_ops([], q, t) == []
+    with pytest.raises(ValueError):
+        oracle.cigar_ops([(0, 0, 4), (3, 5, 2)], q, t)
 
 
 def test_m4_line():

@@ -1,7 +1,8 @@
-"""CIGAR operations written by the device (gba_results.cigar_*), through the C-ABI, against the
-host restatement blasr_amd.emit.cigar_ops applied to the same refined blocks and sequences.
-The reference's own writers are not in its tree: what is checked is that both of this library's
-forms agree operation for operation, and that the operations account for every base."""
+"""CIGAR operations written by the device (gba_results.cigar_*), through the C-ABI, against the CPU
+oracle's column-by-column restatement (oracle/cigar_oracle.c) applied to the same refined blocks and
+sequences; the host writer blasr_amd.emit.cigar_ops must agree with both.  The reference's own writers
+are not in its tree (parity unpinned): what is checked is that the three forms agree operation for
+operation, and that the operations account for every base."""
 import os
 
 import numpy as np
@@ -36,6 +37,7 @@ def _by_code(seq):
 
 def _check(api, synth, batch, pairs, blocks, ops, off, flags, expect_all_ok=True):
     from blasr_amd import _lib, emit
+    from oracle import oracle as cpu_oracle
     n = int(batch["n_pairs"])
     assert int(off[0]) == 0 and int(off[n]) == len(ops)
     assert (np.diff(off.astype(np.int64)) >= 0).all()
@@ -49,10 +51,10 @@ def _check(api, synth, batch, pairs, blocks, ops, off, flags, expect_all_ok=True
         n_ok += 1
         q, t, _ = synth.pair(batch, p)
         kb = blocks[int(k["blk_off"]):int(k["blk_off"]) + int(k["n_blk"])]
-        want = emit.cigar_ops(kb, _by_code(q), _by_code(t), int(k["q_pos"]), int(k["t_pos"]),
-                              use_seq_match=bool(flags & _lib.CIGAR_SEQ_MATCH),
-                              allow_adjacent_indels=bool(flags & _lib.CIGAR_ADJACENT_INDELS))
+        fl = dict(use_seq_match=bool(flags & _lib.CIGAR_SEQ_MATCH), allow_adjacent_indels=bool(flags & _lib.CIGAR_ADJACENT_INDELS))
+        want = cpu_oracle.cigar_ops(kb, q, t, int(k["q_pos"]), int(k["t_pos"]), **fl)
         assert got == want, (p, flags)
+        assert emit.cigar_ops(kb, _by_code(q), _by_code(t), int(k["q_pos"]), int(k["t_pos"]), **fl) == want, (p, flags)
         # every base from the first block to the end of the last one is accounted for (gaps in front of the
         # first block and behind the last are not part of the block list), no two equal operations in a row
         assert sum(c for c, o in got if o in "M=XI") == int(kb[-1]["q_pos"]) + int(kb[-1]["length"]) - int(kb[0]["q_pos"])

@@ -30,8 +30,10 @@ def _case(rng, strand):
     return genome, strand_seq, read, len(left)
 
 
-@pytest.mark.parametrize("strand", [0, 1])
-def test_extend_alignments(mods, oracle, strand):
+@pytest.mark.parametrize("strand,t_pos,slack", [(0, 0, 0), (1, 0, 0), (0, 130, 75), (1, 620, 410)])
+def test_extend_alignments(mods, oracle, strand, t_pos, slack):
+    """t_pos / slack: the candidate's window is wider than its alignment (the normal case after AlignIntervals): t_pos
+    bases in front of the first block, slack behind the last; the prelude of BlasrAlignImpl.hpp:1020-1037 cuts both off."""
     api, refine, L = mods
     rng = np.random.default_rng(100 + strand)
     ctx = api.Context(0)
@@ -39,8 +41,9 @@ def test_extend_alignments(mods, oracle, strand):
     genome, sseq, read, nl = _case(rng, strand)
     assert refine._genome_slice(genome, 1234, 77, strand) == sseq[1234:1234 + 77]
     blk = np.zeros(1, refine.BLOCK_DT); blk[0] = (0, 0, 800)
-    c = refine.AlignmentCandidate(tAlignedSeq=sseq[1600:2400], tAlignedSeqPos=1600, qAlignedSeqPos=nl, blocks=blk, tStrand=strand,
-                                  qAlignedSeq=read[nl:nl + 800], qAlignedSeqLength=800, tAlignedSeqLength=800, nMatch=800, score=-4000)
+    c = refine.AlignmentCandidate(tAlignedSeq=sseq[1600 - t_pos:2400 + slack], tAlignedSeqPos=1600 - t_pos, tPos=t_pos, qAlignedSeqPos=0, qPos=nl,
+                                  blocks=blk, tStrand=strand, qAlignedSeq=read, qAlignedSeqLength=len(read),
+                                  tAlignedSeqLength=800 + t_pos + slack, nMatch=800, score=-4000)
     n = refine.ExtendAlignments(read, [c], genome, params, ctx)
     assert n == 2
     P = refine._kband_params(params, L.KB_EXTEND, ins=params.insertion, dele=params.deletion, max_drops=10)
@@ -68,6 +71,8 @@ def test_extend_alignments(mods, oracle, strand):
         assert len(qs) == l and len(ts) == l
         agree += int((qs == ts).sum())
     assert agree == c.nMatch
+    assert c.tAlignedSeq == sseq[c.tAlignedSeqPos:c.tAlignedSeqPos + len(c.tAlignedSeq)] and len(c.tAlignedSeq) == c.tAlignedSeqLength
+    assert c.tPos + got[-1][1] + got[-1][2] == len(c.tAlignedSeq) and c.qPos + got[-1][0] + got[-1][2] == c.qAlignedSeqLength
     assert c.qInterval[0] < nl - 100 and c.qInterval[1] > nl + 800 + 100
     ctx.close()
 
@@ -171,16 +176,34 @@ def test_cpp_shim_legacy_refine_and_extend(mods, oracle):
         v = [int(x) for x in row.split()]
         assert v[:6] == [c.status, c.score, c.nCells, c.qPos, c.tPos, len(c.blocks)]
         assert v[6:] == [int(x) for b in c.blocks for x in b]
-    # -- extend: the candidate of test_extend_alignments on the forward strand
+    # -- extend: the candidate of test_extend_alignments on the forward strand, its window cut to the alignment; the same
+    # with slack on both sides of the alignment inside a wider window (tPos = 150, then tPos = 700 > the 500 bases an
+    # extension may take), and the legacy branch's interval fields
     genome, sseq, read, nl = _case(rng, 0)
-    blk = np.zeros(1, refine.BLOCK_DT); blk[0] = (0, 0, 800)
-    c = refine.AlignmentCandidate(tAlignedSeq=sseq[1600:2400], tAlignedSeqPos=1600, qAlignedSeqPos=nl, blocks=blk,
-                                  qAlignedSeq=read[nl:nl + 800], qAlignedSeqLength=800, tAlignedSeqLength=800)
-    assert refine.ExtendAlignments(read, [c], genome, refine.MappingParameters(), ctx) == 2
-    text = "1\n%s\n%s 1600 %d 1 0 0 800\n" % (genome.decode(), read.decode(), nl)
+    lines, want = [], []
+    for t_pos, slack in ((0, 0), (150, 90), (700, 300)):
+        blk = np.zeros(1, refine.BLOCK_DT); blk[0] = (0, 0, 800)
+        w0 = 1600 - t_pos
+        c = refine.AlignmentCandidate(tAlignedSeq=sseq[w0:2400 + slack], tAlignedSeqPos=w0, qAlignedSeqPos=0, qPos=nl, tPos=t_pos, blocks=blk,
+                                      qAlignedSeq=read, qAlignedSeqLength=len(read), tAlignedSeqLength=2400 + slack - w0)
+        assert refine.ExtendAlignments(read, [c], genome, refine.MappingParameters(), ctx) == 2
+        want.append(c)
+        lines.append("%s %d %d 0 %d %d 1 0 0 800" % (read.decode(), w0, 2400 + slack - w0, nl, t_pos))
+    for c in want[1:]:          # slack in the window changes nothing: the prelude cuts it off
+        assert (c.qAlignedSeqPos, c.tAlignedSeqPos, c.qPos, c.tPos, c.tAlignedSeq) == (want[0].qAlignedSeqPos, want[0].tAlignedSeqPos, want[0].qPos, want[0].tPos, want[0].tAlignedSeq)
+        assert (c.blocks == want[0].blocks).all()
+    text = "%d\n%s\n%s\n" % (len(lines), genome.decode(), "\n".join(lines))
     out = subprocess.run([exe, "extend"], input=text, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    v = [int(x) for x in out.stdout.split()]
-    assert v[:7] == [0, c.score, c.qAlignedSeqPos, c.tAlignedSeqPos, c.qPos, c.tPos, len(c.blocks)]
-    assert v[7:] == [int(x) for b in c.blocks for x in b]
+    for row, c in zip(out.stdout.strip().split("\n"), want):
+        f = row.split()
+        v = [int(x) for x in f[:10]]
+        assert v == [0, c.score, c.qAlignedSeqPos, c.tAlignedSeqPos, c.qPos, c.tPos, c.qInterval[0], c.qInterval[1], c.tInterval[0], c.tInterval[1]]
+        assert f[10] == c.tAlignedSeq.decode()
+        assert [int(x) for x in f[11:]] == [len(c.blocks)] + [int(x) for b in c.blocks for x in b]
+        # the aligned target string is the genome between the alignment's boundaries, every block inside it
+        assert c.tAlignedSeq == sseq[c.tAlignedSeqPos:c.tAlignedSeqPos + len(c.tAlignedSeq)]
+        last = c.blocks[-1]
+        assert c.tPos + int(last["t_pos"]) + int(last["length"]) == len(c.tAlignedSeq)
+        assert c.qPos + int(last["q_pos"]) + int(last["length"]) == c.qAlignedSeqLength == len(c.qAlignedSeq)
     ctx.close()

@@ -255,3 +255,24 @@ def test_a_profile_that_spells_out_the_matrix_gives_the_plain_results(synth, mon
     assert outs[0][:2] == outs[1][:2]
     assert outs[0][2] < n // 2 and outs[1][2] == n           # lane-per-pair kernels against wave-per-pair kernels
     ctx.close()
+
+
+def test_score_range_guard_counts_the_profile_costs(oracle, synth):
+    """A pair near the row limit whose profile holds the largest costs the kernels take: its scores would leave the
+    cell word (rows x (128 + 127) + columns x 127 reaches 2^24), so it comes back TOO_LONG instead of a wrapped score;
+    a shorter one with the same costs fits and agrees with the oracle."""
+    from blasr_amd import api, _lib
+    ctx = api.Context(0)
+    kw = dict(band=10, ins=5, dele=4)
+    ctx.set_scoring(api.make_scoring(**kw))
+    for length, want_status in ((47000, _lib.PAIR_TOO_LONG), (30000, _lib.PAIR_OK)):
+        batch = synth.compact_blocks(synth.generate(1, read_len=length, len_jitter=0, seed=length))
+        n = len(batch["q_arena"])
+        prof = np.full((n, 11), 127, np.int16).reshape(-1)
+        plain, _, rc = ctx.refine_host(batch)
+        assert rc == 0 and int(plain[0]["status"]) == _lib.PAIR_OK          # the matrix scorer's costs fit either way
+        pairs, blocks, rc = ctx.refine_host(dict(batch, q_profile=prof))
+        assert rc == 0 and int(pairs[0]["status"]) == want_status, (length, int(pairs[0]["status"]))
+        if want_status == _lib.PAIR_OK:
+            _check(oracle, batch, prof, oracle.make_params(**kw), pairs, blocks)
+    ctx.close()

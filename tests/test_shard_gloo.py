@@ -109,3 +109,37 @@ def test_ranks_merge_into_one_array_in_input_order(oracle, synth, tmp_path, worl
     owner.close()
     assert got_p.tobytes() == want_p.tobytes()
     assert got_b.tobytes() == want_b.tobytes()
+
+
+def test_contiguous_ranges_keep_reads_together_and_results_need_no_gather(oracle, synth):
+    """MultiGpuRefiner's partition: contiguous pair ranges cut between reads, balanced by query bases; a range as a
+    batch of its own sees only its stretch of the arenas; the ranks' results one after the other are the batch's
+    results in input order (Segments.merged: two concatenations and one offset per rank)."""
+    batch = synth.generate(60, read_len=300, len_jitter=150, seed=33, decoy_every=5, share_reads=True, ref_len=150_000)
+    want_p, want_b = _oracle_results(oracle, batch)
+    total = sum(batch[k].nbytes for k in ("q_arena", "t_arena", "blocks"))
+    for world in (1, 2, 3, 5, 12, 16):
+        ranges = shard.contiguous_ranges(batch, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == 60 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        if world <= 12:
+            assert all(hi > lo for lo, hi in ranges)                        # 12 reads: nobody idles
+        segs, staged = [], 0
+        for lo, hi in ranges:
+            if lo > 0 and lo < 60:
+                assert batch["read_id"][lo] != batch["read_id"][lo - 1]     # cut between reads
+            sub, nbytes = shard.range_batch(batch, lo, hi)
+            staged += nbytes
+            p, b = _oracle_results(oracle, sub) if hi > lo else (np.zeros(0, _lib.PAIR_RESULT_DT), np.zeros(0, _lib.BLOCK_DT))
+            segs.append((lo, hi, p, b, len(b)))
+        # shared reads are staged once per rank that has candidates of them; nothing else is staged twice
+        assert staged <= total + 1
+        s = shard.Segments(60, segs, 0)
+        mp_, mb_ = s.merged()
+        assert mp_.tobytes() == want_p.tobytes() and mb_.tobytes() == want_b.tobytes()
+        r, blk = s.pair(37)
+        assert int(r["score"]) == int(want_p[37]["score"])
+        assert blk.tobytes() == want_b[int(want_p[37]["blk_off"]):int(want_p[37]["blk_off"]) + int(want_p[37]["n_blk"])].tobytes()
+    # balance by query bases: one long read among short ones gets a rank to itself
+    q_len = np.array([100] * 10 + [5000] + [100] * 10, np.uint32)
+    r = shard.contiguous_ranges({"n_pairs": 21, "q_len": q_len}, 3)
+    assert (10, 11) in r

@@ -54,3 +54,43 @@ def test_no_alloc_entry_point_matches_submit_device(synth):
         _both(api, _lib, ctx, small, torch)
     finally:
         ctx.close()
+
+
+def test_no_alloc_call_leaves_free_device_memory_unchanged(synth):
+    """hipMemGetInfo before and after: a call through gba_submit_device_noalloc on a context whose grow-only buffers are
+    all still empty does not change the free device memory, while the ordinary entry point on the same context does (so
+    the check would see an allocation)."""
+    import torch
+    from blasr_amd import _lib, api
+    warm_ctx = api.Context(0)
+    ctx = None
+    try:
+        def outputs(batch):
+            n = int(batch["n_pairs"])
+            return (torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0"),
+                    torch.zeros((int(batch["q_len"].astype(np.int64).sum()) + n, 3), dtype=torch.int32, device="cuda:0"))
+        # first launches load the kernels' code and may allocate on their own: have them behind us
+        warm_ctx.set_scoring(api.make_scoring())
+        warm = synth.generate(9, read_len=500, len_jitter=200, seed=902)
+        warm_ctx.refine_device(api.to_device(warm), *outputs(warm), no_alloc=True)
+        ctx = api.Context(0)
+        ctx.set_scoring(api.make_scoring())
+        big = synth.generate(120, read_len=2400, len_jitter=1200, seed=901)
+        d = api.to_device(big)
+        pairs, blocks = outputs(big)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info(0)[0]
+        rc, needed = ctx.refine_device(d, pairs, blocks, no_alloc=True)
+        torch.cuda.synchronize()
+        free1 = torch.cuda.mem_get_info(0)[0]
+        assert rc == 0 and needed > 0
+        assert free1 == free0, (free0, free1)
+        want = pairs.cpu().numpy().copy()
+        rc, _ = ctx.refine_device(d, pairs, blocks)
+        torch.cuda.synchronize()
+        assert rc == 0 and torch.cuda.mem_get_info(0)[0] < free1          # the ordinary path grows the context's buffers
+        assert np.array_equal(pairs.cpu().numpy(), want)
+    finally:
+        warm_ctx.close()
+        if ctx is not None:
+            ctx.close()
