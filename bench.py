@@ -9,12 +9,21 @@ is ONE common synthetic read set; rank r (one per GPU) owns the reads with index
 = r (mod N) and all their candidates, generates exactly those, and after the timed
 steps writes their results at the reads' own places into one node-wide array
 (blasr_amd.shard.SharedMerge).  No data-path collective; the only communication is
-the timing barrier / max-reduce.  Per-GPU work is fixed (weak scaling).
+the timing barrier / max-reduce.  --scaling weak (default): per-GPU work is fixed, the
+common set grows with N; --scaling strong: the common set is fixed (--pairs in all) and
+split N ways (BASELINE config 4: "reads sharded across 2/4/8").
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (one process per
+GPU through torch.distributed.run, before anything in this process touches a GPU) and
+fails when fewer than N GPUs are visible; under the driver's own launcher (WORLD_SIZE set)
+it is one of the ranks.
 
 Beside the device-resident rate (`value`) the line carries, on rank 0 at N=1:
   host_to_host  the same batch through gba_submit / gba_wait from and to page-locked
                 host memory (targets as windows of the resident reference)
   cpu_baseline  the CPU oracle on all host cores over a bounded sample of the batch
+  other_workloads  BASELINE configs 3, 4 and 5 device-resident, two steps each
+  end_to_end    reads in, filtered and scored alignments out (read-level harness)
 
 Prints ONE JSON line on rank 0.
 """
@@ -210,6 +219,78 @@ def fixed_band(api, _lib, host, n, threads):
     return r
 
 
+def launch_ranks(n_gpus):
+    """`bench.py --gpus N` started by hand: become the launcher of N ranks of this same command.  Nothing here touches
+    a GPU (counting devices does not initialise one), so the ranks are started as children, never by replacing this
+    process.  GBA_BENCH_BACKEND=gloo: a rehearsal, several ranks may share a GPU."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n_gpus and os.environ.get("GBA_BENCH_BACKEND", "nccl") != "gloo":
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (GBA_BENCH_BACKEND=gloo rehearses with ranks sharing a GPU)" % (n_gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def kernel_name(cfg, tm, n, quad_min):
+    """The fill kernel that ran the bulk of a batch, from the library's own routing."""
+    affine = cfg["mode"] == "affine"
+    if tm["wide_pairs"] * 2 > n:               # most pairs ran wave-per-pair
+        if affine:
+            return "k_fill_quad_affine" if tm["wide_pairs"] >= quad_min and cfg["band"] <= 30 else "k_fill_wide_affine"
+        return "k_fill_wide_cols" if cfg["band"] > 30 else "k_fill_wide<1>"
+    return "k_fill<%s>" % ("true" if affine else "false")
+
+
+def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None):
+    """One of the other BASELINE configurations, device-resident like the headline: generate, one warm-up step, `steps`
+    timed steps; the same definitions of GCUPS and of the fill's share of the int32 VALU peak."""
+    cfg = dict(synth.PRESETS[name])
+    if band is not None:
+        cfg["band"] = band
+    affine = cfg["mode"] == "affine"
+    k = cfg.get("decoy_every", 0) or 1
+    n -= n % k
+    ref = synth.reference(cfg["ref_len"], synth.REF_SEED, cfg.get("n_frac", 0.0))
+    host = synth.generate(n, share_reads=k > 1, ref=ref, **{a: b for a, b in cfg.items() if a != "ref"})
+    d = api.to_device(host, "cuda:0")
+    cap = int(host["q_len"].astype(np.int64).sum() // 4) + n
+    del host
+    out_pairs = torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0")
+    out_blocks = torch.zeros((cap, 3), dtype=torch.int32, device="cuda:0")
+    ctx = api.Context(0, timing=True)
+    ctx.set_scoring(api.make_scoring(band=cfg["band"], max_band=max_band, mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR))
+    rc, _ = ctx.refine_device(d, out_pairs, out_blocks)
+    torch.cuda.synchronize()
+    fill = tb = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rc, _ = ctx.refine_device(d, out_pairs, out_blocks)
+        tm = ctx.timing()
+        fill += tm["fill_ms"]; tb += tm["traceback_ms"]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    res = out_pairs.cpu().numpy().view(_lib.PAIR_RESULT_DT)
+    cells = int(tm["cells"])
+    fill_s = fill / steps / 1e3
+    ops = OPS_PER_CELL[cfg["mode"]]
+    r = {"pairs": n, "read_len": cfg["read_len"], "band": cfg["band"], "gaps": cfg["mode"], "candidates_per_read": k, "rc": rc,
+         "pairs_ok": int((res["status"] == 0).sum()), "ms_per_step": round(dt * 1e3, 3), "gcups": round(cells / dt / 1e9, 2),
+         "kernel": kernel_name(cfg, tm, n, int(os.environ.get("GBA_QUAD_AFFINE_MIN", "10240"))),
+         "fill_ms": round(fill_s * 1e3, 3), "traceback_ms": round(tb / steps, 3), "fill_gcups": round(cells / fill_s / 1e9, 2),
+         "frac": round(cells * ops / fill_s / 1e12 / VALU_PEAK_TOPS, 4), "steps": steps}
+    ctx.close()
+    del d, out_pairs, out_blocks
+    torch.cuda.empty_cache()
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +305,10 @@ def main():
     ap.add_argument("--no-host", action="store_true", help="skip the host-to-host measurement")
     ap.add_argument("--no-guides", action="store_true", help="skip the guide-production measurement")
     ap.add_argument("--no-fixed-band", action="store_true", help="skip the gba_kband (end extension) measurement")
+    ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configurations (other_workloads)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the read-level harness (end_to_end)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = --pairs per GPU (default), strong = --pairs in all, split over the GPUs")
     ap.add_argument("--cigar", type=int, default=None, help="also have the device write CIGAR operations (GBA_CIGAR_* flags); not part of the default line")
     ap.add_argument("--host-steps", type=int, default=6)
     ap.add_argument("--host-contexts", type=int, default=2)
@@ -232,6 +317,10 @@ def main():
     args = ap.parse_args()
     if args.host_child:
         return host_child(args)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
 
     import torch
     from blasr_amd import api, shard, synth, _lib
@@ -239,6 +328,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d started as one of %d ranks: the launcher's --nproc-per-node and --gpus must agree" % (args.gpus, world))
     if world > 1:
         import torch.distributed as dist
         # GBA_BENCH_BACKEND=gloo: rehearsal of the multi-rank path with several ranks on one GPU
@@ -258,6 +349,8 @@ def main():
     mode = cfg["mode"]
     affine = mode == "affine"
     k = cfg.get("decoy_every", 0) or 1
+    if args.scaling == "strong" and world > 1:
+        n //= world                              # one fixed read set, a share per GPU
     n -= n % k                                   # whole reads
     scoring_kw = dict(band=cfg["band"], max_band=args.max_band, mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR)
     scoring = api.make_scoring(**scoring_kw)
@@ -334,22 +427,19 @@ def main():
     fill_s = fill_ms / 1e3 / args.steps
     ops_cell, bytes_cell = OPS_PER_CELL[mode], BYTES_PER_CELL[mode]
     traffic = MEASURED_FILL_TRAFFIC.get((args.workload, n))
-    wide = tm["wide_pairs"] * 2 > n               # most pairs ran wave-per-pair: the bulk kernel is k_fill_wide
-    quad_min = int(os.environ.get("GBA_QUAD_AFFINE_MIN", "10240"))      # the library's switch to four pairs per wave (narrow affine class)
-    kernel = (("k_fill_quad_affine" if tm["wide_pairs"] >= quad_min and cfg["band"] <= 30 else "k_fill_wide_affine") if affine else ("k_fill_wide_cols" if cfg["band"] > 30 else "k_fill_wide<1>")) \
-        if wide else "k_fill<%s>" % ("true" if affine else "false")
+    kernel = kernel_name(cfg, tm, n, int(os.environ.get("GBA_QUAD_AFFINE_MIN", "10240")))      # the library's switch to four pairs per wave
     out = {
         "metric": "banded-DP GCUPS (guided banded alignment, refine stage)",
         "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
         "dtype": "int32", "data": "synthetic",
         "config": {"workload": args.workload, "pairs_per_gpu": n, "read_len": cfg["read_len"],
                    "error": "ins %.2f / del %.2f / sub %.2f" % (cfg["p_ins"], cfg["p_del"], cfg["p_sub"]),
                    "candidates_per_read": k, "band": cfg["band"], "gaps": mode, "reference_len": cfg["ref_len"],
                    "cells_per_step_per_gpu": cells_step, "pairs_ok": ok_all, "pairs_total": n * world,
-                   "parallelism": "one common read set, reads i = rank (mod %d) per GPU, no collective, results merged in input order" % world},
+                   "parallelism": "one common read set of %d pairs, reads i = rank (mod %d) per GPU, no collective, results merged in input order" % (n * world, world)},
         "aligned_reads_per_sec": round(n * args.steps * world / dt, 1),
         "roofline": {
             "bound": "valu-int32", "kernel": kernel,
@@ -468,6 +558,15 @@ def main():
                                                        "sample": "%d pairs in %.1f s (oracle/sdp_oracle.c, one pair per call, %d threads)" % (done, secs, threads)}
     if rank == 0 and world == 1 and not args.no_fixed_band:
         out["fixed_band"] = fixed_band(api, _lib, host, n, None if args.no_cpu else host_cores())
+    if rank == 0 and world == 1 and not args.no_others and args.workload == "c2_10kb_linear":
+        # the other BASELINE configurations, device-resident, at the sizes the measurement plan names for them
+        out["other_workloads"] = {}
+        for key, name, pairs, band in (("c3_20kb_affine", "c3_20kb_affine", 16384, None), ("c5_50kb_band100", "c5_50kb_wide", 2048, 100),
+                                       ("c4_chr20_bestn10", "c4_chr20_bestn10", 163840, None)):
+            try:
+                out["other_workloads"][key] = other_workload(torch, api, synth, _lib, name, pairs, 2, args.max_band, band)
+            except Exception as e:          # a failure here must not cost the headline line
+                out["other_workloads"][key] = {"error": repr(e)[:300]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

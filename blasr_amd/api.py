@@ -470,6 +470,16 @@ class HostPipeline:
         self._t_done = now
         return r
 
+    def rerun_last(self, batch, pairs, blocks, cigar=None):
+        """Runs a batch to completion on the context whose batch wait() returned last (it is idle; the batches still in
+        flight are on the others): for a caller that has to repeat that batch, e.g. with a larger block arena after
+        GBA_E_NOSPACE.  Returns (rc, blocks_needed)."""
+        if self._wait == 0:
+            raise GbaError(_lib.E_STATE)
+        c = self.ctxs[(self._wait - 1) % len(self.ctxs)]
+        c.submit_host(batch, pairs, blocks, cigar=cigar)
+        return c.wait_host()
+
 
 def to_device(batch, device="cuda:0"):
     """Copy a host batch dict to torch CUDA tensors (bit patterns preserved)."""

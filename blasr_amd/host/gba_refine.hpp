@@ -10,10 +10,16 @@
 #define GBA_REFINE_HPP
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <deque>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/gba.h"
@@ -854,6 +860,296 @@ inline void StoreMapQVs(std::vector<AlignmentCandidate *> &alignmentPtrs, const 
         }
     }
 }
+
+// ---- the worker pool of the reference on GPUs ------------------------------------------------------
+// The reference runs -nproc worker threads, each with its own MappingBuffers (Blasr.cpp:1457-1488, :771).  On this path a
+// worker is a context (gba_ctx); HostPipeline is what the workers that share ONE GPU become, MultiGpuRefiner the whole
+// pool: one pipeline per GPU, every batch cut into one contiguous range of reads per GPU, no collective, results in
+// input order (the -start / -stride partition of iblasr/RegisterBlasrOptions.h:93-94 gives every process whole reads
+// too; contiguous ranges instead of a stride keep each GPU's share of the arenas one stretch, so a GPU stages and holds
+// 1 / nGPU of the bytes).
+
+// Several contexts on ONE GPU used in turn, so that host-buffer batches overlap: batch k + 1 is submitted before batch k
+// is waited for, its inputs travel while batch k computes, and batch k's last results travel while batch k + 1 starts.
+// Batches that start together stay together (both wait for their first inputs and both copy their last results out at
+// the same time, with no kernel running in between), so a batch submitted while the one before it has run for less than
+// `stagger` of a batch's usual time is held back inside Submit() for the difference; once apart they stay apart.
+// Set GPU_MAX_HW_QUEUES=16 in the environment before the HIP runtime starts (8 streams per context).
+class HostPipeline {
+public:
+    explicit HostPipeline(int device, int depth = 2, double stagger = 0.4) : stagger_(stagger)
+    {
+        for (int i = 0; i < depth; i++) {
+            gba_ctx *c = nullptr;
+            gba_config cfg{device, 0, nullptr};
+            const int rc = gba_create(&c, &cfg);
+            if (rc != GBA_OK) { for (gba_ctx *x : ctxs_) gba_destroy(x); throw std::runtime_error(std::string("gba_create: ") + gba_strerror(rc)); }
+            ctxs_.push_back(c);
+        }
+    }
+    ~HostPipeline() { for (gba_ctx *c : ctxs_) gba_destroy(c); }
+    HostPipeline(const HostPipeline &) = delete;
+    HostPipeline &operator=(const HostPipeline &) = delete;
+
+    int depth() const { return (int)ctxs_.size(); }
+    gba_ctx *ctx(int i) const { return ctxs_[(size_t)i]; }
+    int SetScoring(const gba_scoring &s) { for (gba_ctx *c : ctxs_) { const int rc = gba_set_scoring(c, &s); if (rc) return rc; } return GBA_OK; }
+    int SetReference(const uint8_t *ref, uint64_t len) { for (gba_ctx *c : ctxs_) { const int rc = gba_set_reference(c, ref, len); if (rc) return rc; } return GBA_OK; }
+    int SetGuideProducer(const gba_sdp_params *p) { for (gba_ctx *c : ctxs_) { const int rc = gba_set_guide_producer(c, p); if (rc) return rc; } return GBA_OK; }
+    // page-locked memory of context i (freed with it)
+    void *HostAlloc(uint64_t bytes, int i = 0) { return gba_host_alloc(ctxs_[(size_t)i], bytes); }
+
+    // gba_submit on the next context in turn; the batch arrays, *out and its buffers stay the caller's until Wait() returns
+    int Submit(const gba_batch &b, gba_results *out)
+    {
+        if (sub_ - wait_ >= ctxs_.size()) return GBA_E_STATE;
+        if (!t_submit_.empty() && service_ > 0 && stagger_ > 0) {
+            const double hold = t_submit_.back() + stagger_ * service_ - Now();
+            if (hold > 0) std::this_thread::sleep_for(std::chrono::duration<double>(hold));
+        }
+        const int rc = gba_submit(ctxs_[sub_ % ctxs_.size()], &b, out);
+        if (rc != GBA_OK) return rc;
+        t_submit_.push_back(Now());
+        sub_++;
+        return GBA_OK;
+    }
+    // gba_wait for the oldest submitted batch
+    int Wait()
+    {
+        if (wait_ >= sub_) return GBA_E_STATE;
+        const int rc = gba_wait(ctxs_[wait_ % ctxs_.size()]);
+        wait_++;
+        const double now = Now(), started = t_submit_.front();
+        t_submit_.pop_front();
+        const double took = now - (have_done_ && t_done_ > started ? t_done_ : started);
+        service_ = service_ > 0 ? 0.5 * service_ + 0.5 * took : took;
+        t_done_ = now; have_done_ = true;
+        return rc;
+    }
+    // Runs a batch to completion on the context whose batch Wait() returned last (it is idle; the batches still in flight
+    // are on the others): for a caller that repeats that batch, e.g. with a larger block arena after GBA_E_NOSPACE.
+    int RerunLast(const gba_batch &b, gba_results *out)
+    {
+        if (wait_ == 0) return GBA_E_STATE;
+        gba_ctx *c = ctxs_[(wait_ - 1) % ctxs_.size()];
+        const int rc = gba_submit(c, &b, out);
+        return rc != GBA_OK ? rc : gba_wait(c);
+    }
+
+private:
+    static double Now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    std::vector<gba_ctx *> ctxs_;
+    size_t sub_ = 0, wait_ = 0;
+    double stagger_, service_ = 0, t_done_ = 0;
+    bool have_done_ = false;
+    std::deque<double> t_submit_;
+};
+
+// The results of the pairs [lo, hi) of a batch as one GPU left them; pairs[k].blk_off indexes `blocks`.
+struct Segment { uint32_t lo = 0, hi = 0; gba_pair_result *pairs = nullptr; gba_block *blocks = nullptr; uint64_t blocks_needed = 0; int rc = GBA_OK; };
+
+class MultiGpuRefiner {
+public:
+    // devices: one worker per entry (a GPU may be named more than once); depth: contexts per worker, used in turn
+    explicit MultiGpuRefiner(const std::vector<int> &devices, int depth = 1, double stagger = 0.4) : depth_(depth)
+    {
+        for (int d : devices) pipes_.emplace_back(new HostPipeline(d, depth, stagger));
+        work_.resize(devices.size() * (size_t)depth);
+        last_needed_.assign(devices.size(), 0);
+        bytes_staged.assign(devices.size(), 0);
+    }
+    size_t workers() const { return pipes_.size(); }
+    HostPipeline &pipe(size_t g) { return *pipes_[g]; }
+    int SetScoring(const gba_scoring &s) { for (auto &p : pipes_) { const int rc = p->SetScoring(s); if (rc) return rc; } return GBA_OK; }
+    int SetReference(const uint8_t *ref, uint64_t len) { for (auto &p : pipes_) { const int rc = p->SetReference(ref, len); if (rc) return rc; } return GBA_OK; }
+    int SetGuideProducer(const gba_sdp_params *sp) { for (auto &p : pipes_) { const int rc = p->SetGuideProducer(sp); if (rc) return rc; } return GBA_OK; }
+
+    // What the caller knows about the blocks a worker's share of a batch will hold (otherwise: what its last batch needed;
+    // a first batch: one block per four query bases).  Too small a figure costs that worker a second run, nothing else.
+    void ExpectBlocks(uint64_t perWorker) { last_needed_.assign(last_needed_.size(), perWorker); }
+
+    // Pair ranges, one per worker, that tile the batch in order: cut only between reads (read_id[p], null: every pair is
+    // its own read) and balanced by query bases, the predictor of a pair's DP cells.
+    static std::vector<std::pair<uint32_t, uint32_t>> ContiguousRanges(const gba_batch &b, const uint32_t *read_id, size_t world)
+    {
+        const uint32_t n = b.n_pairs;
+        std::vector<std::pair<uint32_t, uint32_t>> out(world, {0u, 0u});
+        if (n == 0) return out;
+        std::vector<uint32_t> starts;               // first pair of every read
+        std::vector<uint64_t> before;               // query bases in front of it
+        uint64_t acc = 0;
+        for (uint32_t p = 0; p < n; p++) {
+            if (p == 0 || !read_id || read_id[p] != read_id[p - 1]) { starts.push_back(p); before.push_back(acc); }
+            acc += b.q_len[p];
+        }
+        const size_t R = starts.size();
+        std::vector<uint32_t> cuts{0};
+        size_t k_prev = 0;
+        for (size_t r = 1; r < world; r++) {
+            const double want = (double)acc * (double)r / (double)world;
+            size_t k = (size_t)(std::lower_bound(before.begin(), before.end(), want, [](uint64_t a, double w) { return (double)a < w; }) - before.begin());
+            if (k > 0 && k < R && want - (double)before[k - 1] < (double)before[k] - want) k--;      // the nearest read boundary
+            if (R >= world) k = std::min(std::max(k, k_prev + 1), R - (world - r));              // nobody idles when there are reads enough
+            k = std::max(k, k_prev);
+            cuts.push_back(k < R ? starts[k] : n);
+            k_prev = k;
+        }
+        cuts.push_back(n);
+        for (size_t r = 0; r < world; r++) out[r] = {cuts[r], cuts[r + 1]};
+        return out;
+    }
+
+    // Starts the batch on every worker (gba_submit does not block) and returns; Wait() collects it.  The batch arrays stay
+    // the caller's until then.  Batches with packed reads or a cost profile go to one context (or HostPipeline) whole.
+    int Submit(const gba_batch &b, const uint32_t *read_id = nullptr, bool wantBlocks = true)
+    {
+        if (flight_.size() >= (size_t)depth_) return GBA_E_STATE;
+        if (b.q_packed || b.q_profile) return GBA_E_UNSUPPORTED;
+        const size_t slot = sub_ % (size_t)depth_;
+        Ticket t;
+        t.wantBlocks = wantBlocks; t.slot = slot;
+        const auto ranges = ContiguousRanges(b, read_id, pipes_.size());
+        for (size_t g = 0; g < pipes_.size(); g++) {
+            Work &w = work_[g * (size_t)depth_ + slot];
+            w.lo = ranges[g].first; w.hi = ranges[g].second;
+            const uint32_t n = w.hi - w.lo;
+            w.submitted = false;
+            if (n == 0) continue;
+            // this range as a batch of its own: per-pair arrays shifted, the three arenas cut to the stretch its pairs point
+            // into and the offsets rebased, so that the GPU stages and holds its own share only
+            gba_batch &sb = w.batch;
+            sb = b;
+            sb.n_pairs = n;
+            sb.q_len = b.q_len + w.lo; sb.t_len = b.t_len + w.lo;
+            if (b.n_blk) sb.n_blk = b.n_blk + w.lo;
+            if (b.t_rc) sb.t_rc = b.t_rc + w.lo;
+            uint64_t staged = 0, qsum = 0;
+            Rebase(b.q_off, b.q_len, w.lo, n, b.q_arena_bytes, w.q_off, &sb.q_arena, 1, &sb.q_arena_bytes, &staged);
+            sb.q_off = w.q_off.data();
+            if (b.t_arena) Rebase(b.t_off, b.t_len, w.lo, n, b.t_arena_bytes, w.t_off, &sb.t_arena, 1, &sb.t_arena_bytes, &staged);
+            else w.t_off.assign(b.t_off + w.lo, b.t_off + w.hi);                       // windows of the resident reference: absolute
+            sb.t_off = w.t_off.data();
+            if (b.blocks) {
+                const uint8_t *base = (const uint8_t *)b.blocks;
+                Rebase(b.blk_off, b.n_blk, w.lo, n, b.n_blocks_total, w.b_off, &base, sizeof(gba_block), &sb.n_blocks_total, &staged);
+                sb.blocks = (const gba_block *)base; sb.blk_off = w.b_off.data();
+            }
+            bytes_staged[g] = staged;
+            for (uint32_t p = 0; p < n; p++) qsum += sb.q_len[p];
+            const uint64_t cap = !wantBlocks ? 0 : last_needed_[g] ? last_needed_[g] + last_needed_[g] / 8 + 64 : qsum / 4 + n + 64;
+            int rc = Buffers(g, w, n, cap);
+            if (rc != GBA_OK) return rc;
+            if ((rc = pipes_[g]->Submit(sb, &w.res)) != GBA_OK) return rc;
+            w.submitted = true;
+        }
+        flight_.push_back(t);
+        sub_++;
+        return GBA_OK;
+    }
+
+    // Blocks until the oldest submitted batch is complete on every worker; segs (one per worker, in order) then tile the
+    // batch in input order.  A worker whose block arena, sized from its last batch, was too small runs its range again at
+    // the size it reported.  Returns the first error of any worker.
+    int Wait(std::vector<Segment> *segs)
+    {
+        if (flight_.empty()) return GBA_E_STATE;
+        const Ticket t = flight_.front();
+        flight_.pop_front();
+        segs->clear();
+        int rc_all = GBA_OK;
+        for (size_t g = 0; g < pipes_.size(); g++) {
+            Work &w = work_[g * (size_t)depth_ + t.slot];
+            Segment s;
+            s.lo = w.lo; s.hi = w.hi;
+            if (w.submitted) {
+                int rc = pipes_[g]->Wait();
+                if (rc == GBA_E_NOSPACE && t.wantBlocks) {
+                    rc = Buffers(g, w, w.hi - w.lo, w.res.blocks_needed + 64);
+                    if (rc == GBA_OK) rc = pipes_[g]->RerunLast(w.batch, &w.res);
+                }
+                last_needed_[g] = w.res.blocks_needed;
+                s.pairs = w.res.pairs; s.blocks = w.res.blocks; s.blocks_needed = w.res.blocks_needed; s.rc = rc;
+                if (rc != GBA_OK && rc_all == GBA_OK) rc_all = rc;
+            }
+            segs->push_back(s);
+        }
+        return rc_all;
+    }
+
+    // The segments as the two arrays one context would have returned: pairs in input order, blocks packed in input order,
+    // every blk_off rewritten (two sequential copies and one prefix per worker).
+    static void Merge(const std::vector<Segment> &segs, std::vector<gba_pair_result> *pairs, std::vector<gba_block> *blocks)
+    {
+        pairs->clear(); blocks->clear();
+        for (const Segment &s : segs) {
+            const uint64_t base = blocks->size();
+            const size_t at = pairs->size();
+            if (s.pairs) pairs->insert(pairs->end(), s.pairs, s.pairs + (s.hi - s.lo));
+            for (size_t k = at; k < pairs->size(); k++) (*pairs)[k].blk_off += base;
+            if (s.blocks) blocks->insert(blocks->end(), s.blocks, s.blocks + s.blocks_needed);
+        }
+    }
+
+    std::vector<uint64_t> bytes_staged;      // arena bytes of the last batch, per worker
+
+private:
+    struct Work {
+        uint32_t lo = 0, hi = 0;
+        bool submitted = false;
+        gba_batch batch{};
+        gba_results res{};
+        std::vector<uint64_t> q_off, t_off, b_off;
+        gba_pair_result *pairs = nullptr; uint64_t pairs_cap = 0;
+        gba_block *blocks = nullptr; uint64_t blocks_cap = 0;
+    };
+    struct Ticket { bool wantBlocks = true; size_t slot = 0; };
+
+    // offsets of pairs [lo, lo + n) into an arena of `extent` elements: the stretch they cover becomes the arena
+    static void Rebase(const uint64_t *off, const uint32_t *len, uint32_t lo, uint32_t n, uint64_t extent, std::vector<uint64_t> &out,
+                       const uint8_t **arena, size_t esz, uint64_t *new_extent, uint64_t *staged)
+    {
+        uint64_t first = UINT64_MAX, last = 0;
+        for (uint32_t p = lo; p < lo + n; p++) {
+            const uint64_t o = off[p], l = len[p];
+            if (l == 0 || o > extent || l > extent - o) continue;          // the kernels refuse such a pair without touching it
+            first = std::min(first, o); last = std::max(last, o + l);
+        }
+        if (first > last) { first = 0; last = 0; }
+        out.resize(n);
+        for (uint32_t p = 0; p < n; p++) out[p] = off[lo + p] - first;     // a refused pair's offset wraps: it stays outside the arena
+        *arena += first * esz;
+        *new_extent = last - first;
+        *staged += (last - first) * esz;
+    }
+
+    // page-locked result buffers of a worker's slot, grow-only, from the context that fills them
+    int Buffers(size_t g, Work &w, uint32_t n, uint64_t cap)
+    {
+        const int ci = (int)(&w - &work_[g * (size_t)depth_]);
+        if (w.pairs_cap < n) {
+            w.pairs = (gba_pair_result *)pipes_[g]->HostAlloc(((uint64_t)n + n / 8 + 1) * sizeof(gba_pair_result), ci);
+            if (!w.pairs) return GBA_E_NOMEM;
+            w.pairs_cap = (uint64_t)n + n / 8 + 1;
+        }
+        if (w.blocks_cap < cap) {
+            w.blocks = (gba_block *)pipes_[g]->HostAlloc((cap + cap / 8 + 1) * sizeof(gba_block), ci);
+            if (!w.blocks) return GBA_E_NOMEM;
+            w.blocks_cap = cap + cap / 8 + 1;
+        }
+        w.res = gba_results{};
+        w.res.pairs = w.pairs;
+        w.res.blocks = cap ? w.blocks : nullptr;
+        w.res.blocks_capacity = cap;
+        return GBA_OK;
+    }
+
+    int depth_;
+    std::vector<std::unique_ptr<HostPipeline>> pipes_;
+    std::vector<Work> work_;                 // [worker][slot]
+    std::vector<uint64_t> last_needed_;
+    std::deque<Ticket> flight_;
+    size_t sub_ = 0;
+};
 
 }  // namespace gba
 #endif

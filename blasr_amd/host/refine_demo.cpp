@@ -17,12 +17,17 @@
 //            (its window is the genome from tAlignedSeqPos over windowLength bases, the blocks are relative to qPos / tPos):
 //            the -extend step (ExtendAlignments); prints per candidate
 //            status score qAlignedSeqPos tAlignedSeqPos qPos tPos qStart qEnd tStart tEnd tAlignedSeq nblk blocks...
+//   pool     the worker pool: every input line is one candidate of read (line index / 3) (three candidates per read); the batch
+//            runs (a) on one context, (b) twice in a row through a HostPipeline of two contexts on GPU 0, (c) twice through a
+//            MultiGpuRefiner of three workers with two contexts each, all on GPU 0, the first time with a block arena guessed
+//            far too small; prints "ok <pairs> <blocks> <staged bytes of each worker>" when (b) and (c) give (a)'s bytes
 //   mapqv    no GPU: stdin is n, then "qStart qEnd rawProbScore" per candidate of ONE read; prints their mapQVs
 //   filters  no GPU: stdin is n, then "tIndex tBegin tEnd score pctSimilarity nBlocks" per candidate of ONE read, in order;
 //            runs RemoveLowQualityAlignments, then RemoveOverlappingAlignments (iblasr/BlasrAlignImpl.hpp:381-382) and
 //            prints the input indices of the survivors
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 
 #include "gba_refine.hpp"
@@ -117,6 +122,85 @@ int main(int argc, char **argv)
             for (std::string *s : {&q.insertionQV, &q.deletionQV, &q.substitutionQV}) for (char &ch : *s) ch = (char)(ch - 33);
             qvs.push_back(q);
         }
+    }
+    if (mode == "pool") {
+        std::string qa, ta;
+        std::vector<uint64_t> q_off, t_off, b_off;
+        std::vector<uint32_t> q_len, t_len, n_blk, read_id;
+        std::vector<gba_block> blk;
+        for (size_t i = 0; i < n; i++) {
+            q_off.push_back(qa.size()); q_len.push_back((uint32_t)reads[i].size()); qa += reads[i];
+            t_off.push_back(ta.size()); t_len.push_back((uint32_t)cands[i].tAlignedSeq.size()); ta += cands[i].tAlignedSeq;
+            b_off.push_back(blk.size()); n_blk.push_back((uint32_t)cands[i].blocks.size());
+            for (auto &b : cands[i].blocks) blk.push_back(gba_block{b.qPos, b.tPos, b.length});
+            read_id.push_back((uint32_t)(i / 3));
+        }
+        gba_batch b{};
+        b.n_pairs = (uint32_t)n;
+        b.q_arena = (const uint8_t *)qa.data(); b.q_off = q_off.data(); b.q_len = q_len.data(); b.q_arena_bytes = qa.size();
+        b.t_arena = (const uint8_t *)ta.data(); b.t_off = t_off.data(); b.t_len = t_len.data(); b.t_arena_bytes = ta.size();
+        b.blocks = blk.data(); b.blk_off = b_off.data(); b.n_blk = n_blk.data(); b.n_blocks_total = blk.size();
+        const gba_scoring sc = gba::ScoringFromParams(gba::MappingParameters());
+        const uint64_t cap = qa.size() + n;
+        // (a) one context
+        std::vector<gba_pair_result> wantP(n);
+        std::vector<gba_block> wantB(cap);
+        uint64_t needed = 0;
+        {
+            gba_ctx *one = nullptr;
+            gba_config cfg{0, 0, nullptr};
+            int rc = gba_create(&one, &cfg);
+            if (rc == GBA_OK) rc = gba_set_scoring(one, &sc);
+            gba_results r{};
+            r.pairs = wantP.data(); r.blocks = wantB.data(); r.blocks_capacity = cap;
+            if (rc == GBA_OK) rc = gba_submit(one, &b, &r);
+            if (rc == GBA_OK) rc = gba_wait(one);
+            if (rc != GBA_OK) { std::fprintf(stderr, "one context: %s\n", gba_strerror(rc)); return 1; }
+            needed = r.blocks_needed;
+            gba_destroy(one);
+        }
+        auto same = [&](const gba_pair_result *p, const gba_block *bl, uint64_t nb) {
+            return nb == needed && std::memcmp(p, wantP.data(), n * sizeof(gba_pair_result)) == 0 && std::memcmp(bl, wantB.data(), needed * sizeof(gba_block)) == 0;
+        };
+        // (b) two contexts on the GPU, two batches in flight
+        {
+            gba::HostPipeline pipe(0, 2, 0.4);
+            if (pipe.SetScoring(sc) != GBA_OK) return 1;
+            std::vector<gba_pair_result> p0(n), p1(n);
+            std::vector<gba_block> b0(cap), b1(cap);
+            gba_results r0{}, r1{};
+            r0.pairs = p0.data(); r0.blocks = b0.data(); r0.blocks_capacity = cap;
+            r1.pairs = p1.data(); r1.blocks = b1.data(); r1.blocks_capacity = cap;
+            if (pipe.Submit(b, &r0) != GBA_OK || pipe.Submit(b, &r1) != GBA_OK) { std::fprintf(stderr, "pipeline submit\n"); return 1; }
+            gba_results r2{};
+            if (pipe.Submit(b, &r2) != GBA_E_STATE) { std::fprintf(stderr, "a third batch in flight was accepted\n"); return 1; }
+            if (pipe.Wait() != GBA_OK || pipe.Wait() != GBA_OK || pipe.Wait() != GBA_E_STATE) { std::fprintf(stderr, "pipeline wait\n"); return 1; }
+            if (!same(p0.data(), b0.data(), r0.blocks_needed) || !same(p1.data(), b1.data(), r1.blocks_needed)) { std::fprintf(stderr, "pipeline results differ\n"); return 1; }
+        }
+        // (c) the pool: three workers of two contexts each
+        gba::MultiGpuRefiner pool({0, 0, 0}, 2, 0.0);
+        if (pool.SetScoring(sc) != GBA_OK) return 1;
+        std::vector<gba::Segment> segs;
+        std::vector<gba_pair_result> gotP;
+        std::vector<gba_block> gotB;
+        pool.ExpectBlocks(1);            // far too few: every worker's first run ends in GBA_E_NOSPACE and is repeated at size
+        for (int round = 0; round < 2; round++) {
+            if (pool.Submit(b, read_id.data()) != GBA_OK || pool.Submit(b, read_id.data()) != GBA_OK) { std::fprintf(stderr, "pool submit\n"); return 1; }
+            for (int k = 0; k < 2; k++) {
+                const int rc = pool.Wait(&segs);
+                if (rc != GBA_OK) { std::fprintf(stderr, "pool wait: %s\n", gba_strerror(rc)); return 1; }
+                for (size_t g = 0; g < segs.size(); g++) {
+                    if (g && segs[g].lo != segs[g - 1].hi) { std::fprintf(stderr, "segments do not tile the batch\n"); return 1; }
+                    if (segs[g].lo < n && segs[g].lo > 0 && read_id[segs[g].lo] == read_id[segs[g].lo - 1]) { std::fprintf(stderr, "a read was cut\n"); return 1; }
+                }
+                gba::MultiGpuRefiner::Merge(segs, &gotP, &gotB);
+                if (gotP.size() != n || !same(gotP.data(), gotB.data(), gotB.size())) { std::fprintf(stderr, "pool results differ (round %d)\n", round); return 1; }
+            }
+        }
+        std::printf("ok %zu %llu", n, (unsigned long long)needed);
+        for (uint64_t v : pool.bytes_staged) std::printf(" %llu", (unsigned long long)v);
+        std::printf(" %zu\n", qa.size() + ta.size() + blk.size() * sizeof(gba_block));
+        return 0;
     }
     gba_ctx *ctx = nullptr;
     gba_config cfg{0, 0, nullptr};

@@ -256,8 +256,8 @@ class MultiGpuRefiner:
                 continue
             rc, needed = self.pipes[g].wait()
             if rc == _lib.E_NOSPACE and want_blocks:         # the arena guessed from the last batch was too small: once more, at size
-                pairs, blocks = self._submit_range(g, slot, sub, True, needed + 64)
-                rc, needed = self.pipes[g].wait()
+                blocks = self._buffer(g, slot, "blocks", needed + 64, _lib.BLOCK_DT)
+                rc, needed = self.pipes[g].rerun_last(sub, pairs, blocks)
             self._last_needed[g] = needed
             rc_all = rc_all or rc
             segs.append((lo, hi, pairs, blocks, needed))

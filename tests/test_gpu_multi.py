@@ -9,10 +9,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_multi_gpu_refiner_equals_one_context(oracle, synth, world):
-    """One batch, reads dealt round-robin over the contexts with all their candidates, every context
+    """One batch, a contiguous range of reads (all their candidates with them) per context, every context
     running at the same time: the merged result is byte-identical to one context's, whatever the
     number of contexts (the reference's multi-thread output needs a sort to compare,
-    /root/reference/ctest/fofn.t:17)."""
+    /root/reference/ctest/fofn.t:17); every context stages its own share of the arenas only."""
     from blasr_amd import api, shard
     ref = synth.reference(800_000, n_frac=0.01)
     batch = synth.generate(330, read_len=1800, len_jitter=600, seed=77, decoy_every=6, share_reads=True, ref=ref)
@@ -27,6 +27,16 @@ def test_multi_gpu_refiner_equals_one_context(oracle, synth, world):
         got_p, got_b, rc = m.refine_host(batch)
         assert rc == 0
         assert got_p.tobytes() == want_p.tobytes() and got_b.tobytes() == want_b.tobytes()
+        total = sum(batch[k].nbytes for k in ("q_arena", "t_arena", "blocks"))
+        assert sum(m.bytes_staged) <= total and max(m.bytes_staged) < 0.6 * total * 2 / world        # a share each, not the whole batch
+        # a second batch reuses the pinned result buffers, sized from what the first one needed; the segments in order are
+        # the batch in input order without any copy
+        segs = m.refine_host_segments(batch)
+        assert segs.rc == 0 and [s[0] for s in segs] == [r[0] for r in shard.contiguous_ranges(batch, world)]
+        for p in (0, 137, 329):
+            r, blk = segs.pair(p)
+            assert r.tobytes() [:24] == want_p[p].tobytes()[:24] and int(r["score"]) == int(want_p[p]["score"])
+            assert blk.tobytes() == want_b[int(want_p[p]["blk_off"]):int(want_p[p]["blk_off"]) + int(want_p[p]["n_blk"])].tobytes()
         # the same through windows of a reference every context holds
         m.set_reference(ref)
         got_p, got_b, rc = m.refine_host(synth.as_windows(batch) | {"read_id": batch["read_id"]})
@@ -40,6 +50,33 @@ def test_multi_gpu_refiner_equals_one_context(oracle, synth, world):
         m.set_guide_producer(sp)
         got_p, got_b, rc = m.refine_host(seqs)
         assert rc == 0 and got_p.tobytes() == want_p.tobytes() and got_b.tobytes() == want_b.tobytes()
+    finally:
+        m.close()
+        one.close()
+
+
+def test_two_contexts_per_worker_overlap_batches(synth):
+    """depth 2: a second batch is submitted while the first one runs (its inputs travel under the first one's kernels); both
+    come back complete and in order, equal to what one context returns; a block arena guessed too small is run again at size."""
+    from blasr_amd import api, shard
+    a = synth.generate(200, read_len=1500, len_jitter=500, seed=5)
+    b = synth.generate(260, read_len=900, len_jitter=300, seed=6)
+    one = api.Context(0)
+    one.set_scoring(api.make_scoring())
+    want = [one.refine_host(x) for x in (a, b)]
+    m = shard.MultiGpuRefiner([0, 0], depth=2, stagger=0.0)
+    try:
+        m.set_scoring(api.make_scoring())
+        m._last_needed = [8, 8]                      # as if the last batch had needed next to nothing: forces the retry
+        m.submit(a); m.submit(b)
+        for w in want:
+            s = m.wait()
+            gp, gb = s.merged()
+            assert s.rc == 0 and gp.tobytes() == w[0].tobytes() and gb.tobytes() == w[1].tobytes()
+        # interval output: no blocks anywhere
+        s = m.refine_host_segments(a, want_blocks=False)
+        gp, gb = s.merged()
+        assert s.rc == 0 and len(gb) == 0 and (gp["score"] == want[0][0]["score"]).all() and (gp["q_end"] == want[0][0]["q_end"]).all()
     finally:
         m.close()
         one.close()

@@ -258,3 +258,25 @@ def test_dense_anchors_bypass_the_guide_producer():
     params = refine.MappingParameters(sdpBypassThreshold=0.75)
     refine.GuidesFromAnchorsOrSDP(read, [c], anchors, params, ctx=None)
     assert [tuple(int(v) for v in b) for b in c.blocks] == [(0, 0, 80), (90, 95, 90)] and c.status == 0
+
+
+@pytest.mark.gpu
+def test_cpp_worker_pool_equals_one_context(synth):
+    """refine_demo pool: gba::HostPipeline (two contexts on the GPU, two batches in flight) and gba::MultiGpuRefiner (three
+    workers of two contexts each, contiguous ranges of whole reads, block arenas guessed too small at first) return the
+    bytes one context returns, and every worker stages only its share of the arenas."""
+    from blasr_amd import build
+    exe = build.HOST_DEMO
+    assert os.path.exists(exe), "run python -m blasr_amd.build"
+    batch = synth.generate(96, read_len=900, len_jitter=400, seed=99)
+    lines = ["96"]
+    for i in range(96):
+        q, t, blk = synth.pair(batch, i)
+        lines.append("%s %s %d %s" % (bytes(q).decode(), bytes(t).decode(), len(blk),
+                                      " ".join("%d %d %d" % (b["q_pos"], b["t_pos"], b["length"]) for b in blk)))
+    out = subprocess.run([exe, "pool"], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    f = out.stdout.split()
+    assert f[0] == "ok" and int(f[1]) == 96 and int(f[2]) > 96
+    staged, total = [int(x) for x in f[3:6]], int(f[6])
+    assert sum(staged) == total and max(staged) < 0.5 * total
