@@ -18,6 +18,8 @@ NOALLOC_SCRATCH_BYTES = 64 << 20
  PAIR_END_OUT_OF_BAND, PAIR_TOO_WIDE, PAIR_TOO_LONG, PAIR_TOO_MANY) = range(9)
 MODE_LINEAR, MODE_AFFINE, MODE_KBAND = 0, 1, 2
 TIE_DIAG_LEFT_UP, TIE_DIAG_UP_LEFT = 0, 1
+ALIGN_GLOBAL, ALIGN_LOCAL = 0, 1
+PAIR_NO_ALIGNMENT = 9
 FLAG_TIMING = 1
 CIGAR_SEQ_MATCH, CIGAR_ADJACENT_INDELS = 1, 2
 CIGAR_OPS = "MIDNSHP=X"
@@ -53,7 +55,7 @@ class Scoring(C.Structure):
         ("band", C.c_int32), ("max_band", C.c_int32),
         ("mode", C.c_int32), ("tie_break", C.c_int32),
         ("kband_k", C.c_int32), ("stats_affine", C.c_int32),
-        ("n_extra", C.c_int32), ("extra", Rescorer * MAX_EXTRA),
+        ("n_extra", C.c_int32), ("extra", Rescorer * MAX_EXTRA), ("align_type", C.c_int32),
     ]
 
 

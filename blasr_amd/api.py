@@ -17,7 +17,7 @@ from ._lib import (BLOCK_DT, PAIR_RESULT_DT, Batch, Config, GbaError, Guides, Kb
 def make_scoring(match=-5, mismatch=6, n_score=0, ins=5, dele=4, indel=5, band=10, max_band=250,
                  mode=_lib.MODE_LINEAR, tie_break=_lib.TIE_DIAG_LEFT_UP, affine_open=10,
                  affine_extend=0, stats_affine=0, stats_affine_open=0, stats_affine_extend=0,
-                 kband_k=0, sub=None, extra=()):
+                 kband_k=0, sub=None, extra=(), align_type=_lib.ALIGN_GLOBAL):
     """gba_scoring with BLASR's defaults: SMRTDistanceMatrix-like match/mismatch
     (iblasr/RegisterBlasrOptions.h:358-360), the refine scorer's gap costs
     (iblasr/BlasrUtilsImpl.hpp:630-631 read as ins=5, del=4), rescoring with indel=5 both
@@ -38,6 +38,7 @@ def make_scoring(match=-5, mismatch=6, n_score=0, ins=5, dele=4, indel=5, band=1
     s.stats_affine_open, s.stats_affine_extend = stats_affine_open, stats_affine_extend
     s.band, s.max_band, s.mode, s.tie_break = band, max_band, mode, tie_break
     s.kband_k, s.stats_affine = kband_k, stats_affine
+    s.align_type = align_type       # ALIGN_GLOBAL, or ALIGN_LOCAL: free start, end in the band's cheapest cell (linear gaps only)
     # further scorers the finished path is rescored with: dicts with sub (5x5), ins, dele and,
     # for affine gap runs, affine=1, affine_open, affine_extend
     s.n_extra = len(extra)

@@ -49,6 +49,7 @@ constexpr int32_t UNREACH = 0x20000000;      // unbiased words at or above this 
 constexpr uint32_t MAX_ROWS = 65535;         // keeps biased words inside int32 (see gba_set_scoring)
 constexpr uint32_t MAX_ROWS_AFFINE = 32767;  // affine words carry one more tag bit
 constexpr uint32_t MAX_COLS = 1u << 20;
+constexpr int N_PAIR32 = 18, N_PAIR64 = 5;   // per-pair scratch arrays of 4 and 8 bytes (gba_ctx::b_pair32 / b_pair64)
 // Classes of the lane-per-pair fill kernel: a pair's class is the smallest LDS row buffer
 // (32 << class slots) that holds its widest "shift + width".  Each non-empty class is one launch.
 constexpr int NCLS = 5;                      // lane-per-pair classes of 32, 64, 128 slots, then the two wave-per-pair classes
@@ -99,6 +100,9 @@ struct Dev {                  // per-batch device state, SoA per pair
     uint32_t *qS, *tS, *Q, *T, *rows, *cols, *wcap, *span, *lo_last, *cls, *order, *recdw;
     uint64_t *row_off, *col_off, *word_off, *rec_off, *ncells;
     int32_t *dp_score;
+    // GBA_ALIGN_LOCAL: the cheapest cell of each pair, written by the fill: its row, column, the first column of that row and
+    // the position of that row's meta dword in the pair's records -- where the traceback begins instead of at (Q, T)
+    uint32_t *end_i, *end_j, *end_lo, *end_ptr;
     Plan *plan;
     // arenas
     uint32_t *stream;         // guide stream words
@@ -929,7 +933,14 @@ __device__ __forceinline__ int32_t wave_scan_min(int32_t v, int32_t identity)
 // fetched one row ahead by eleven lanes and handed round through LDS.  The deletion cost now differs from column to
 // column, so the cost of reaching column k from column j along the row is P(k) - P(j) with P the prefix sum of the
 // row's deletion costs (one more wave scan per chunk), where the fixed cost had (k - j) * del.
-template <int NB, bool QV = false>
+//
+// LOCAL (gba_scoring.align_type GBA_ALIGN_LOCAL: GuidedAlign(..., Local, ...), /root/reference/iblasr/BlasrAlignImpl.hpp:1418-1421):
+// every cell may also begin the alignment at cost 0 -- one more candidate, a word of score 0 (plus the row's bias) with the
+// arrow code 3, folded into the moves from the previous row before the scan, so that the deletions chained along the row
+// may start from it too -- and the alignment ends in the cheapest cell of the band: every lane keeps the cheapest of
+// its own cells (the earliest on ties), the wave picks the first of them in row-major order at the end and leaves its
+// row, column and record position for the traceback.
+template <int NB, bool QV = false, bool LOCAL = false>
 __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t cls)
 {
     __shared__ int32_t ptab[16];
@@ -954,6 +965,8 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t 
     uint32_t W = 0, Wp = 0, dsh = 0, roff = 0;
     const int16_t *prow = QV ? d.prof + (d.q_off[p] + d.qS[p]) * 11 : nullptr;      // row r >= 1 uses prow[(r - 1) * 11 ..]
     int32_t pnext = QV && Q >= 1u && lane < 11 ? (int32_t)prow[lane] : 0;
+    int32_t bsc = 0;                                    // LOCAL: this lane's cheapest cell: its score (<< 5, bias removed), ...
+    uint32_t bi = 0, bj = 0, blo = 0, bptr = 0, lo = 0; // ... row, column, first column and meta dword of its row; first column of the current row
     __syncthreads();
     for (uint32_t r = 0; r <= Q; r++) {
         if constexpr (QV) {
@@ -994,8 +1007,11 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t 
         __syncthreads();
         // carries into the first chunk: the diagonal predecessor of column 0 and "the cell left of it"
         uint32_t cdiag = dsh >= 1u && dsh - 1u < Wp ? ring[dsh - 1u] : INFW;
-        int32_t hc = r == 0 ? -D : (int32_t)INFW;       // row 0: column j costs j deletions
+        int32_t hc = r == 0 && !LOCAL ? -D : (int32_t)INFW;       // row 0: column j costs j deletions (LOCAL: every cell of it begins an alignment)
         const uint32_t nd = (W + 15u) >> 4;
+        lo += dsh;
+        const int32_t rbias = (int32_t)(r * 4096u);     // what the substitution table's bias has added to every cell of this row
+        const int32_t startw = rbias + (3 << 3);        // LOCAL: "the alignment begins here"
         // WIDE_NB chunks of 64 columns at a time: their loads, candidate words and local scans are
         // independent of each other; only the carries (scalar) link a chunk to the one before it
         for (uint32_t c0 = 0; c0 < W; c0 += 64 * WIDE_NB) {
@@ -1014,14 +1030,14 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t 
                     const int32_t subc = ptab[ti], insc = ptab[5], delc = r == 0u ? fc.del : ptab[6 + ti];
                     const int32_t m = (int32_t)(((uint32_t)(subc + 128) << 5) + diag);
                     const int32_t u = (int32_t)up[b] + fc.cU + (insc - fc.ins) * 32;
-                    xv[b] = min(m, u);
+                    xv[b] = LOCAL ? min(min(m, u), startw) : min(m, u);
                     pd[b] = (int32_t)wave_scan_sum((uint32_t)(delc * 32));          // P(k): the row's deletion costs up to and including column k of the chunk
                     incl[b] = wave_scan_min((int32_t)((uint32_t)xv[b] & ~TAGS) - pd[b], BIG);
                 } else {
                     const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);
                     const int32_t m = (int32_t)((sb << 5) + diag);
                     const int32_t u = (int32_t)up[b] + fc.cU;
-                    xv[b] = min(m, u);                      // best of the two moves from the previous row
+                    xv[b] = LOCAL ? min(min(m, u), startw) : min(m, u);     // best of the two moves from the previous row
                     incl[b] = wave_scan_min((int32_t)((uint32_t)xv[b] & ~TAGS) - lane * D, BIG);
                 }
             }
@@ -1032,6 +1048,11 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t 
                     const int32_t lc = (QV ? min(excl, hc) + pd[b] : min(excl + lane * D, hc + (lane + 1) * D)) + codeL;
                     const uint32_t best = (uint32_t)min(xv[b], lc);
                     ring[c0 + 64 * b + lane] = (up[b] & TAGS) | (best & ~TAGS);
+                    if constexpr (LOCAL) {
+                        const uint32_t col = c0 + 64u * (uint32_t)b + (uint32_t)lane;
+                        const int32_t sc = (int32_t)(best & ~TAGS) - rbias;
+                        if (col < W && sc < bsc) { bsc = sc; bi = r; bj = lo + col; blo = lo; bptr = roff + nd; }
+                    }
                     // score of the chunk's last column: its own best over this chunk's columns, or the carry
                     if constexpr (QV) hc = min(__builtin_amdgcn_readlane(incl[b], 63), hc) + __builtin_amdgcn_readlane(pd[b], 63);
                     else hc = min(__builtin_amdgcn_readlane(incl[b], 63) + 63 * D, hc + 64 * D);
@@ -1049,6 +1070,18 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t 
         if (lane == 0) rec[roff + nd] = word & ROW_META_MASK;
         roff += nd + 1u;
         __syncthreads();
+    }
+    if constexpr (LOCAL) {
+        // the cheapest cell of the band, the first in row-major order among equals (every cell is some lane's)
+        int32_t m = bsc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
+        unsigned long long key = bsc == m ? (unsigned long long)bi << 32 | bj : ~0ull, kmin = key;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = __shfl_xor(kmin, o, 64); kmin = x < kmin ? x : kmin; }
+        if (m >= 0) { if (lane == 0) { d.status[p] = GBA_PAIR_NO_ALIGNMENT; d.dp_score[p] = 0; } }
+        else if (key == kmin) { d.end_i[p] = bi; d.end_j[p] = bj; d.end_lo[p] = blo; d.end_ptr[p] = bptr; d.dp_score[p] = m >> 5; }
+        return;
     }
     if (lane == 0) {
         const int32_t v = (int32_t)(ring[fslot] & ~TAGS) - (int32_t)Q * (128 << 5);
@@ -1727,7 +1760,9 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
 constexpr int WT_WIN = 4096;      // record dwords per refill
 constexpr int WT_TC = 2048;       // target codes (bytes) per refill
 
-template <bool AFF>
+// LOCAL: the walk begins in the cell the fill left in Dev::end_* and ends at the first cell that carries the arrow code 3
+// ("the alignment begins behind this cell"); gap bases are counted inside the aligned stretch only.
+template <bool AFF, bool LOCAL = false>
 __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_pair_result *res, uint32_t cls)
 {
     constexpr uint32_t CSHIFT = AFF ? 2u : 4u, CMASK = AFF ? 3u : 15u, BITS = AFF ? 8u : 2u;
@@ -1751,7 +1786,8 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
     // The walk is wave-uniform: every lane follows the same path, LDS values are made scalar right
     // after they are read, so the whole state machine runs on the scalar unit; only lane 0 stores.
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)v); };
-    uint32_t i = Q, j = T, lo = uni(d.lo_last[p]), nb = 0, run = 0;
+    uint32_t i = LOCAL ? uni(d.end_i[p]) : Q, j = LOCAL ? uni(d.end_j[p]) : T, lo = uni(LOCAL ? d.end_lo[p] : d.lo_last[p]), nb = 0, run = 0;
+    const uint32_t ei = i, ej = j;
     uint32_t nM = 0, ndiag = 0, nopen = 0, prev_op = 0;
     int32_t score = 0;
     uint32_t budget = (Q + T + 2u) * (AFF ? 3u : 1u);   // affine paths spend an extra step on every gap-state change
@@ -1759,7 +1795,7 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
     bool ok = true, done = false, look_ahead = true;
     int32_t pend_v = 0;
     int32_t lane_score = 0, lane_x0 = 0, lane_x1 = 0;   // substitution costs of the runs taken lanes side by side, summed over the lanes at the end
-    int32_t ptr = (int32_t)uni(d.recdw[p]) - 1;         // meta dword of the current row
+    int32_t ptr = LOCAL ? (int32_t)uni(d.end_ptr[p]) : (int32_t)uni(d.recdw[p]) - 1;         // meta dword of the current row
     while (!done) {
         // refill: records [rb, rb + WT_WIN) ending at ptr, target codes [jb, jb + WT_TC) ending at column j
         const int32_t rb = ptr - (WT_WIN - 1);
@@ -1867,6 +1903,7 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
             uint32_t mv;
             if constexpr (!AFF) {
                 const uint32_t a = cell & 3u;
+                if (LOCAL && a == 3u) { done = true; break; }          // the alignment begins behind this cell
                 mv = a == 0u ? 0u : a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : 4u;
             } else {
                 const uint32_t a = (cell >> 3) & 7u;
@@ -1917,7 +1954,7 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
     if (lane != 0) return;
     gba_pair_result &R = res[p];
     if (!ok) { d.status[p] = GBA_PAIR_UNREACHABLE; return; }
-    const uint32_t nI = Q - ndiag, nD = T - ndiag;
+    const uint32_t nI = (LOCAL ? ei - i : Q) - ndiag, nD = (LOCAL ? ej - j : T) - ndiag;
     score += gap_score(tc_.affine, tc_.ins, tc_.del, tc_.aopen, tc_.aext, nI, nD, nopen);
     R.n_blk = nb; R.score = score;
     d.span[p] = nb;
@@ -2658,7 +2695,7 @@ struct gba_ctx {
     Buf b_ref;                       // reference for batches without a target arena (gba_set_reference)
     uint64_t ref_len = 0;
     Buf s_trc;
-    Buf b_pair32[14], b_pair64[5], b_needed;
+    Buf b_pair32[N_PAIR32], b_pair64[N_PAIR64], b_needed;
     Slot slot[NSLOT];
     // host-buffer batches: device copies of the caller's batch, the copy streams, the worker thread
     Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res, s_cigoff, s_gout;
@@ -2748,6 +2785,7 @@ Dev sub_dev(const Dev &g, uint32_t p0, uint32_t cnt, Slot &sl)
     if (d.guide_status) d.guide_status += p0;
     d.status += p0; d.qS += p0; d.tS += p0; d.Q += p0; d.T += p0; d.rows += p0; d.cols += p0; d.wcap += p0;
     d.span += p0; d.lo_last += p0; d.cls += p0; d.order += p0; d.recdw += p0;
+    d.end_i += p0; d.end_j += p0; d.end_lo += p0; d.end_ptr += p0;
     d.row_off += p0; d.col_off += p0; d.word_off += p0; d.rec_off += p0; d.ncells += p0; d.dp_score += p0;
     d.plan = (Plan *)sl.b_plan.ptr;
     return d;
@@ -2792,7 +2830,8 @@ int phase_guide(gba_ctx *c, Slot &sl, Dev &d)
     // times the instructions per cell but fill the GPU from a few thousand pairs on.  Below wave_pairs
     // pairs the whole batch runs one wave per pair.
     const bool affine = sc.mode == GBA_MODE_AFFINE;
-    const int lane_classes = d.prof || d.n < (affine ? c->wave_pairs_affine : c->wave_pairs) ? 0      // quality-value costs: the wave-per-pair kernels have them
+    const bool local = sc.align_type == GBA_ALIGN_LOCAL;      // the free-start / best-cell end rule lives in the wave-per-pair kernels
+    const int lane_classes = local || d.prof || d.n < (affine ? c->wave_pairs_affine : c->wave_pairs) ? 0      // quality-value costs: the wave-per-pair kernels have them
                            : affine ? (c->affine_top_slots ? LANE_CLS_AFFINE + 1 : LANE_CLS_AFFINE) : LANE_CLS_LINEAR;
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(SCAN_T), 0, sl.s, d, lane_classes, 1, affine ? c->affine_top_slots : 128u);
     HIPCHK(c, hipGetLastError());
@@ -2819,9 +2858,11 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
     hipLaunchKernelGGL(k_results_init, dim3((d.n + 255) / 256), dim3(256), 0, s, d, res);
     HIPCHK(c, hipEventRecord(sl.t_fill0, s));
     const bool aff = sc.mode == GBA_MODE_AFFINE;
+    const bool local = sc.align_type == GBA_ALIGN_LOCAL;    // linear gaps only (gba_set_scoring)
     auto launch_tb = [&](int k, hipStream_t st) {          // a wave-per-pair class
         const uint32_t cnt = pl.cls_count[k];
         if (aff) hipLaunchKernelGGL(k_traceback_wide<true>, dim3(cnt), dim3(64), 0, st, d, c->tbc, res, (uint32_t)k);
+        else if (local) hipLaunchKernelGGL((k_traceback_wide<false, true>), dim3(cnt), dim3(64), 0, st, d, c->tbc, res, (uint32_t)k);
         else hipLaunchKernelGGL(k_traceback_wide<false>, dim3(cnt), dim3(64), 0, st, d, c->tbc, res, (uint32_t)k);
     };
     // The lane-per-pair traceback serves the lane classes AND the narrow wave-per-pair class (order[0 .. first pair of the
@@ -2854,12 +2895,16 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
             if (k == CLS_WIDE) {
                 if (aff && d.prof) hipLaunchKernelGGL((k_fill_wide_affine<false, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else if (aff) hipLaunchKernelGGL((k_fill_wide_affine<false>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+                else if (local && d.prof) hipLaunchKernelGGL((k_fill_wide<4, true, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+                else if (local) hipLaunchKernelGGL((k_fill_wide<4, false, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else if (d.prof) hipLaunchKernelGGL((k_fill_wide<4, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else hipLaunchKernelGGL(k_fill_wide_cols, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
             } else {
                 if (aff && d.prof) hipLaunchKernelGGL((k_fill_wide_affine<true, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else if (aff && cnt >= c->quad_affine_min) hipLaunchKernelGGL(k_fill_quad_affine, dim3((cnt + 3) / 4), dim3(64), 0, st, d, c->fc, (uint32_t)k, cnt);
                 else if (aff) hipLaunchKernelGGL((k_fill_wide_affine<true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+                else if (local && d.prof) hipLaunchKernelGGL((k_fill_wide<1, true, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
+                else if (local) hipLaunchKernelGGL((k_fill_wide<1, false, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else if (d.prof) hipLaunchKernelGGL((k_fill_wide<1, true>), dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
                 else hipLaunchKernelGGL(k_fill_wide<1>, dim3(cnt), dim3(64), 0, st, d, c->fc, (uint32_t)k);
             }
@@ -2880,7 +2925,7 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
     if (wave_on_main[CLS_WIDE]) launch_tb(CLS_WIDE, s);
     // a batch that ran on the wave kernels altogether and leaves the lane-per-pair traceback with too few waves to hide
     // its walk (one dependent chain per pair, however few pairs): the narrow wave class is walked one wave per pair too
-    if (pl.cls_base[CLS_WNARROW] == 0 && pl.cls_count[CLS_WNARROW] > 0 && pl.cls_count[CLS_WNARROW] <= c->tb_wave_max) launch_tb(CLS_WNARROW, s);
+    if (pl.cls_base[CLS_WNARROW] == 0 && pl.cls_count[CLS_WNARROW] > 0 && (local || pl.cls_count[CLS_WNARROW] <= c->tb_wave_max)) launch_tb(CLS_WNARROW, s);
     else if (pl.cls_base[CLS_WIDE] > 0) launch_tb_lanes(s);
     HIPCHK(c, hipGetLastError());
     for (int a = 0; a < NAUXS; a++)
@@ -3073,8 +3118,8 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
         else if (cig) { HIPCHK(c, hipMemsetAsync(cig_off, 0, 8, c->slot[0].s)); HIPCHK(c, hipStreamSynchronize(c->slot[0].s)); }
         return GBA_OK;
     }
-    for (int i = 0; i < 14; i++) { int rc = ensure(c, c->b_pair32[i], (size_t)n * 4); if (rc) return rc; }
-    for (int i = 0; i < 5; i++) { int rc = ensure(c, c->b_pair64[i], (size_t)n * 8); if (rc) return rc; }
+    for (int i = 0; i < N_PAIR32; i++) { int rc = ensure(c, c->b_pair32[i], (size_t)n * 4); if (rc) return rc; }
+    for (int i = 0; i < N_PAIR64; i++) { int rc = ensure(c, c->b_pair64[i], (size_t)n * 8); if (rc) return rc; }
     { int rc = ensure(c, c->b_needed, 16); if (rc) return rc; }
     for (auto &sl : c->slot) { int rc = ensure(c, sl.b_plan, sizeof(Plan)); if (rc) return rc; }
     Dev g;
@@ -3100,6 +3145,8 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
     g.dp_score = (int32_t *)c->b_pair32[11].ptr;
     g.wcap = (uint32_t *)c->b_pair32[12].ptr;
     g.recdw = (uint32_t *)c->b_pair32[13].ptr;
+    g.end_i = (uint32_t *)c->b_pair32[14].ptr; g.end_j = (uint32_t *)c->b_pair32[15].ptr;
+    g.end_lo = (uint32_t *)c->b_pair32[16].ptr; g.end_ptr = (uint32_t *)c->b_pair32[17].ptr;
     g.row_off = (uint64_t *)c->b_pair64[0].ptr; g.col_off = (uint64_t *)c->b_pair64[1].ptr;
     g.rec_off = (uint64_t *)c->b_pair64[2].ptr; g.ncells = (uint64_t *)c->b_pair64[3].ptr;
     g.word_off = (uint64_t *)c->b_pair64[4].ptr;
@@ -3357,6 +3404,7 @@ const char *gba_strerror(int code)
     case GBA_PAIR_TOO_WIDE: return "pair: band row too wide";
     case GBA_PAIR_TOO_LONG: return "pair: too many rows or columns";
     case GBA_PAIR_TOO_MANY: return "pair: too many k-mer matches to chain";
+    case GBA_PAIR_NO_ALIGNMENT: return "pair: nothing aligns (local end rule)";
     default: return "unknown code";
     }
 }
@@ -3475,6 +3523,8 @@ int gba_set_scoring(gba_ctx *c, const gba_scoring *s)
     if (s->n_extra < 0 || s->n_extra > GBA_MAX_EXTRA) return GBA_E_INVALID;
     if (s->band < 0 || s->max_band < 0 || s->band > 30000 || s->max_band > 30000) return GBA_E_INVALID;
     if (s->mode == GBA_MODE_KBAND && (s->kband_k < 0 || s->kband_k > 30000)) return GBA_E_INVALID;
+    if (s->align_type != GBA_ALIGN_GLOBAL && s->align_type != GBA_ALIGN_LOCAL) return GBA_E_INVALID;
+    if (s->align_type == GBA_ALIGN_LOCAL && s->mode != GBA_MODE_LINEAR) return GBA_E_UNSUPPORTED;      // the reference's one Local call is GuidedAlign
     // The fill kernels keep substitution costs in a +128-biased byte table and cell words in int32
     // with 5 low tag bits (affine: 6): |cost| <= 127 keeps the table in bytes.  Whether a pair's
     // scores fit the word is a per-pair matter (rows x row-move cost + columns x deletion cost,
@@ -3573,8 +3623,8 @@ int gba_submit_device_noalloc(gba_ctx *c, const gba_batch *b, gba_results *out)
     if (!c->fixed_base) return GBA_E_HIP;             // hipGetSymbolAddress failed in gba_create
     // The ctx's own (allocated, grow-only) buffers are set aside for the duration of the call and the
     // same pipeline runs on buffers carved from the fixed scratch, as one part on slot 0.
-    Buf *all[14 + 5 + 1 + 5 * NSLOT];
-    Buf saved[14 + 5 + 1 + 5 * NSLOT];
+    Buf *all[N_PAIR32 + N_PAIR64 + 1 + 5 * NSLOT];
+    Buf saved[N_PAIR32 + N_PAIR64 + 1 + 5 * NSLOT];
     int k = 0;
     for (auto &x : c->b_pair32) all[k++] = &x;
     for (auto &x : c->b_pair64) all[k++] = &x;

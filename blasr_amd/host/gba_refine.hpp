@@ -82,7 +82,7 @@ inline void MatrixFromParams(const MappingParameters &p, gba_scoring &s)
 
 // ids: the DP runs with idsScoreFn (a batch that brings cost profiles), the one scorer that receives
 // params.affineOpen / affineExtend (:643-644)
-inline gba_scoring ScoringFromParams(const MappingParameters &p, bool ids = false)
+inline gba_scoring ScoringFromParams(const MappingParameters &p, bool ids = false, int alignType = GBA_ALIGN_GLOBAL)
 {
     gba_scoring s{};
     MatrixFromParams(p, s);
@@ -96,6 +96,7 @@ inline gba_scoring ScoringFromParams(const MappingParameters &p, bool ids = fals
     s.mode = p.affineAlign ? GBA_MODE_AFFINE : GBA_MODE_LINEAR;
     s.tie_break = p.tieBreak;
     s.stats_affine = p.affineAlign ? 1 : 0;
+    s.align_type = alignType;
     return s;
 }
 
@@ -240,11 +241,12 @@ public:
     // one submit/wait for everything added; copy-back of :733-772.  Returns the gba return code.
     // wantBlocks false: interval / summary output (printFormat Interval, SummaryPrint, :992-1000) prints only
     // what the pair results hold, so no block is packed or copied out.
-    int Run(const MappingParameters &params, bool wantBlocks = true)
+    // alignType GBA_ALIGN_LOCAL: the end rule of GuidedAlign(..., Local, ...) (iblasr/BlasrAlignImpl.hpp:1418-1421)
+    int Run(const MappingParameters &params, bool wantBlocks = true, int alignType = GBA_ALIGN_GLOBAL)
     {
         const uint32_t n = (uint32_t)cands_.size();
         if (n == 0) return GBA_OK;
-        gba_scoring sc = ScoringFromParams(params, !prof_.empty());
+        gba_scoring sc = ScoringFromParams(params, !prof_.empty(), alignType);
         int rc = gba_set_scoring(ctx_, &sc);
         if (rc != GBA_OK) return rc;
         if (t_arena_.empty()) t_arena_.push_back('N');
@@ -428,6 +430,24 @@ inline int AlignAndRefineCandidates(const std::string &read, std::vector<Alignme
         c.qAlignedSeqLength = p.rows; c.tAlignedSeqLength = p.cols;
     }
     return GBA_OK;
+}
+
+// The GuidedAlign overload that takes only the two sequences: it chains matches of sdpTupleSize bases itself and runs the
+// banded DP around that chain.  AlignSubreadToAlignmentTarget aligns every subread of a ZMW to the window its CCS (or
+// longest subread) mapped to with it: GuidedAlign(subread, alignedRefSequence, idsScoreFn, 12, params.sdpIns, params.sdpDel,
+// params.indelRate, mappingBuffers, exploded, Local, computeProbIsFalse, 6) (iblasr/BlasrAlignImpl.hpp:1418-1421), then
+// ComputeAlignmentStats with distScoreFn2 (:1448-1450).  Here: SDPAlignCandidates with the short tuple, then the guided DP
+// with band `bandSize` and the Local end rule over the chain's span (profile: the IDS scorer's costs for the read, or null).
+inline int GuidedAlignFromSequences(const std::string &read, std::vector<AlignmentCandidate *> &alignmentPtrs, const MappingParameters &params,
+                                    gba_ctx *ctx, int bandSize = 12, int sdpTupleSize = 6, const std::vector<int16_t> *profile = nullptr)
+{
+    MappingParameters p = params;
+    p.sdpTupleSize = sdpTupleSize; p.guidedAlignBandSize = bandSize; p.affineAlign = false;
+    int rc = SDPAlignCandidates(read, alignmentPtrs, p, ctx);
+    if (rc != GBA_OK) return rc;
+    RefineBatch batch(ctx);
+    for (AlignmentCandidate *c : alignmentPtrs) batch.Add(read, c, profile);
+    return batch.Run(p, true, GBA_ALIGN_LOCAL);
 }
 
 // The -global branch of RefineAlignment (:648-675) for all candidates of one read: the whole subread

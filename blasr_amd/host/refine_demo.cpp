@@ -8,6 +8,8 @@
 //            for each candidate (what a parsing loop does)
 //   global   run the -global branch (RefineGlobal) on each (read, candidate) instead
 //   sdp      the guides come from the device first (SDPAlignCandidates: the blocks of the input are ignored), then the batch
+//   ccs      GuidedAlignFromSequences on each (read, candidate): guides from 6-mers, band 12, the Local end rule (the blocks of
+//            the input are ignored)
 //   fused    SDPAlign and RefineAlignment in one submit (AlignAndRefineCandidates; the blocks of the input are ignored)
 //   intervals  run without a block arena and print per candidate: status score nBlocks qStart qEnd tStart tEnd
 //   qv       every candidate line carries five more strings behind its blocks (insertionQV deletionQV deletionTag substitutionQV
@@ -221,6 +223,11 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < n && rc == GBA_OK; i++) {
             std::vector<gba::AlignmentCandidate *> one{&cands[i]};
             rc = gba::RefineAlignments(reads[i], one, params, ctx);
+        }
+    } else if (mode == "ccs") {
+        for (size_t i = 0; i < n && rc == GBA_OK; i++) {
+            std::vector<gba::AlignmentCandidate *> one{&cands[i]};
+            rc = gba::GuidedAlignFromSequences(reads[i], one, params, ctx);
         }
     } else if (fused) {
         params.sortRefinedAlignments = false;

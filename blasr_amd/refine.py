@@ -97,7 +97,7 @@ STATS_SCORER_AFFINE_OPEN = 0       # distScoreFn2.affineOpen  (ComputeAlignmentS
 STATS_SCORER_AFFINE_EXTEND = 0     # distScoreFn2.affineExtend
 
 
-def scoring_from_params(p: MappingParameters, ids: bool = False):
+def scoring_from_params(p: MappingParameters, ids: bool = False, align_type: int = _lib.ALIGN_GLOBAL):
     """distScoreFn(SMRTDistanceMatrix, params.deletion, params.insertion) read as ctor(ins, del)
     (:630-631) and distScoreFn2(indel, indel) (:633-634); band per :706-731.  The affine costs of
     both scorers are the constructor defaults above, NOT params.affineOpen / affineExtend.
@@ -112,7 +112,7 @@ def scoring_from_params(p: MappingParameters, ids: bool = False):
                         tie_break=p.tieBreak, affine_open=p.affineOpen if ids else DIST_SCORER_AFFINE_OPEN,
                         affine_extend=p.affineExtend if ids else DIST_SCORER_AFFINE_EXTEND,
                         stats_affine=1 if p.affineAlign else 0, stats_affine_open=STATS_SCORER_AFFINE_OPEN,
-                        stats_affine_extend=STATS_SCORER_AFFINE_EXTEND, sub=p.scoreMatrix)
+                        stats_affine_extend=STATS_SCORER_AFFINE_EXTEND, sub=p.scoreMatrix, align_type=align_type)
 
 
 def compute_drift(blocks):
@@ -308,7 +308,7 @@ def GuidesFromAnchorsOrSDP(read: bytes, cands: List[AlignmentCandidate], anchors
 
 
 def GuidedAlignFromSequences(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx,
-                             bandSize: int = 12, sdpTupleSize: int = 6):
+                             bandSize: int = 12, sdpTupleSize: int = 6, qv=None):
     """The GuidedAlign overload that takes only the two sequences: it chains matches of sdpTupleSize
     bases itself and runs the banded DP around that chain.  AlignSubreadToAlignmentTarget uses it to
     align every subread of a ZMW to the window its CCS (or longest subread) mapped to:
@@ -316,18 +316,19 @@ def GuidedAlignFromSequences(read: bytes, cands: List[AlignmentCandidate], param
     params.indelRate, mappingBuffers, exploded, Local, computeProbIsFalse, 6)
     (/root/reference/iblasr/BlasrAlignImpl.hpp:1418-1421), then ComputeAlignmentStats with
     distScoreFn2 (:1448-1450).  Here: SDPAlignCandidates with the short tuple, then the refine stage
-    with band `bandSize`, all candidates of the read in one batch each.  What differs from that call
-    site: the DP runs on the distance matrix with params.insertion / params.deletion, not on the
-    QV-aware IDS scorer (its formulas are libcpp's and need per-base quality values), and it is
-    anchored at the chain's first and last block (the overload's Local end handling is libcpp's)."""
+    with band `bandSize`, all candidates of the read in one batch each:
+    the DP region runs from the chain's first block to its last and the Local end rule (gba.h, GBA_ALIGN_LOCAL) lets the
+    alignment begin and end anywhere inside it; libcpp's own Local handling is not in the reference tree (unpinned).  qv:
+    the read's quality values; with them (and params.ignoreQualities off) the DP runs on the IDS scorer's costs."""
     import dataclasses
     p = dataclasses.replace(params, sdpTupleSize=sdpTupleSize, guidedAlignBandSize=bandSize, useGuidedAlign=True,
-                            doGlobalAlignment=False, refineAlignments=True)
+                            doGlobalAlignment=False, refineAlignments=True, affineAlign=False)
     SDPAlignCandidates(read, cands, p, ctx)
-    return RefineAlignments(read, cands, p, ctx)
+    return RefineAlignments(read, cands, p, ctx, qv=qv, align_type=_lib.ALIGN_LOCAL)
 
 
-def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx, want_blocks: bool = True, qv=None):
+def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: MappingParameters, ctx, want_blocks: bool = True, qv=None,
+                     align_type: int = _lib.ALIGN_GLOBAL):
     """Batched RefineAlignments (:905-923): all candidates of the read in one submit.
     want_blocks False: for interval / summary output (printFormat Interval, SummaryPrint, :992-1000), which
     prints only what the pair results hold: no block leaves the device.
@@ -351,7 +352,7 @@ def RefineAlignments(read: bytes, cands: List[AlignmentCandidate], params: Mappi
         if params.sortRefinedAlignments:
             cands.sort(key=lambda c: c.score)
         return cands
-    ctx.set_scoring(scoring_from_params(params, ids=use_qv))
+    ctx.set_scoring(scoring_from_params(params, ids=use_qv, align_type=align_type))
     batch = build_batch(read, cands)
     if use_qv:
         batch["q_profile"] = ids_profile(read, qv, params)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GBA_VERSION 370   /* major*10000 + minor*100 + patch */
+#define GBA_VERSION 380   /* major*10000 + minor*100 + patch */
 
 /* return codes of the entry points */
 enum {
@@ -49,13 +49,28 @@ enum {
                                       reaches 2^24 (affine 2^23): the scores would not fit the kernels' cell words (a batch
                                       with a q_profile is bounded with 127, affine 63, in place of the largest matrix / gap cost);
                                       gba_sdp_device: a read or window of more than 65535 bases */
-    GBA_PAIR_TOO_MANY = 8          /* gba_sdp_device only: more maximal matches than max_fragments, or more than
+    GBA_PAIR_TOO_MANY = 8,         /* gba_sdp_device only: more maximal matches than max_fragments, or more than
                                       64 x max_fragments k-mer hits (a repeat): no guide is produced */
+    GBA_PAIR_NO_ALIGNMENT = 9      /* GBA_ALIGN_LOCAL only: no cell of the band scores below zero: nothing aligns */
 };
 
 enum { GBA_MODE_LINEAR = 0,   /* replaces GuidedAlign,       BlasrUtilsImpl.hpp:713-716, :727-730 */
        GBA_MODE_AFFINE = 1,   /* replaces AffineGuidedAlign, BlasrUtilsImpl.hpp:707-710, :721-724 */
        GBA_MODE_KBAND  = 2 }; /* replaces KBandAlign(Global), BlasrUtilsImpl.hpp:657-661          */
+
+/* End rule of the guided DP (gba_scoring.align_type).
+ * GBA_ALIGN_GLOBAL: from the first cell of the DP region (first guide block's start) to its last (last block's end):
+ *   RefineAlignment's calls, iblasr/BlasrUtilsImpl.hpp:707-730 (..., Global, false).
+ * GBA_ALIGN_LOCAL: the alignment may begin in any cell of the band at no cost and ends in the cheapest cell of the band:
+ *   GuidedAlign(subread, alignedRefSequence, idsScoreFn, 12, ..., exploded, Local, computeProbIsFalse, 6) of
+ *   AlignSubreadToAlignmentTarget, iblasr/BlasrAlignImpl.hpp:1418-1421 (CCS and -concordant).  Linear gaps with guide
+ *   blocks only (GBA_E_UNSUPPORTED otherwise); such batches run on the wave-per-pair kernels.  What libcpp does with Local
+ *   inside the guided DP is not in the reference tree (unpinned); here: a cell takes the free start only when that is
+ *   strictly cheaper than every move into it, the end is the first cheapest cell in row-major order, and a pair whose
+ *   band holds no negative score gets GBA_PAIR_NO_ALIGNMENT.  q_pos / t_pos, rows / cols and ncells still describe the
+ *   whole DP region and blocks stay relative to q_pos / t_pos; n_ins / n_del count the gaps inside the aligned stretch
+ *   (q_start .. q_end, t_start .. t_end) only. */
+enum { GBA_ALIGN_GLOBAL = 0, GBA_ALIGN_LOCAL = 1 };
 
 /* tie-break among equal candidates of the match state */
 enum { GBA_TIE_DIAG_LEFT_UP = 0, GBA_TIE_DIAG_UP_LEFT = 1 };
@@ -102,6 +117,7 @@ typedef struct {
     int32_t stats_affine;       /* nonzero: rescoring charges each gap run open + length*extend */
     int32_t n_extra;            /* 0..GBA_MAX_EXTRA further scorers, results in gba_pair_result.extra_score */
     gba_rescorer extra[GBA_MAX_EXTRA];
+    int32_t align_type;         /* GBA_ALIGN_* */
 } gba_scoring;
 
 /* one gap-free run of the alignment: the reference's blasr::Block (BlasrUtilsImpl.hpp:745-746) */

@@ -41,12 +41,21 @@
 #define GBO_INF 0x3fffffff
 
 enum { GBO_OK = 0, GBO_EMPTY_GUIDE = 1, GBO_BAD_GUIDE = 2, GBO_UNREACHABLE = 3, GBO_NOSPACE = 4,
-       GBO_END_OUT_OF_BAND = 5 };
+       GBO_END_OUT_OF_BAND = 5, GBO_NO_ALIGNMENT = 9 };
+
+/* End rule of the guided DP.  GLOBAL: from the region's first cell to its last (RefineAlignment's calls,
+ * /root/reference/iblasr/BlasrUtilsImpl.hpp:707-730).  LOCAL (the GuidedAlign(..., Local, ...) call of
+ * AlignSubreadToAlignmentTarget, /root/reference/iblasr/BlasrAlignImpl.hpp:1418-1421): the alignment may begin
+ * in any cell of the band at no cost and ends in the cheapest cell of the band -- Smith-Waterman's rule in
+ * this file's lower-is-better scores.  What libcpp's GuidedAlign does with Local is not in the reference
+ * tree: UNPINNED, stated here as: a cell takes the free start only when it is strictly cheaper than every
+ * move into it; the end is the first cheapest cell in row-major order; an alignment needs a negative score. */
+enum { GBO_ALIGN_GLOBAL = 0, GBO_ALIGN_LOCAL = 1 };
 
 enum { GBO_MODE_LINEAR = 0, GBO_MODE_AFFINE = 1, GBO_MODE_KBAND = 2 };
 
 /* arrows */
-enum { A_NONE = 0, A_DIAG = 1, A_LEFT = 2, A_UP = 3, A_DELCLOSE = 4, A_INSCLOSE = 5 };
+enum { A_NONE = 0, A_DIAG = 1, A_LEFT = 2, A_UP = 3, A_DELCLOSE = 4, A_INSCLOSE = 5, A_START = 6 };
 enum { G_NONE = 0, G_OPEN = 1, G_EXTEND = 2 };
 
 typedef struct { uint32_t q_pos, t_pos, length; } gbo_block;
@@ -62,6 +71,7 @@ typedef struct {
     int32_t tie_break;      /* 0: Diagonal, Left, Up   1: Diagonal, Up, Left */
     int32_t kband_k;        /* GBO_MODE_KBAND only */
     int32_t stats_affine;   /* nonzero: rescoring charges gap runs open + L*extend */
+    int32_t align_type;     /* GBO_ALIGN_*; LOCAL with linear gaps and guide blocks only */
 } gbo_params;
 
 typedef struct {
@@ -288,6 +298,9 @@ int gbo_align_qv(const uint8_t *q, uint32_t q_len, const uint8_t *t, uint32_t t_
     res->rows = (uint32_t)(qEnd - qStart); res->cols = (uint32_t)(tEnd - tStart);
 
     const int affine = (P->mode == GBO_MODE_AFFINE);
+    const int local = (P->align_type == GBO_ALIGN_LOCAL);
+    if (local && P->mode != GBO_MODE_LINEAR) { res->status = GBO_BAD_GUIDE; return res->status; }
+    int best_r = -1, best_t = 0, best_s = 0;        /* LOCAL: the cheapest cell so far */
     int32_t *S = (int32_t *)scratch(BUF_S, sizeof(int32_t) * (size_t)ncells);
     uint8_t *A = (uint8_t *)scratch(BUF_A, (size_t)ncells);
     int32_t *SI = NULL, *SD = NULL; uint8_t *AI = NULL, *AD = NULL;
@@ -309,7 +322,7 @@ int gbo_align_qv(const uint8_t *q, uint32_t q_len, const uint8_t *t, uint32_t t_
             if (tt < tStart - 1) continue;
             if (tt > tEnd - 1) break;               /* past the end of the target slice */
             int64_t cur = cell_index(g, n, r, tt);
-            if (r == 0 && tt == tStart - 1) { S[cur] = 0; A[cur] = A_NONE; continue; }
+            if (r == 0 && tt == tStart - 1) { S[cur] = 0; A[cur] = local ? A_START : A_NONE; continue; }
             int64_t mi = (r > 0 && tt >= tStart) ? cell_index(g, n, r - 1, tt - 1) : -1;
             int64_t ui = (r > 0) ? cell_index(g, n, r - 1, tt) : -1;
             int64_t li = (tt >= tStart) ? cell_index(g, n, r, tt - 1) : -1;
@@ -339,15 +352,21 @@ int gbo_align_qv(const uint8_t *q, uint32_t q_len, const uint8_t *t, uint32_t t_
                 if (SD[cur] < best) { best = SD[cur]; arrow = A_DELCLOSE; }
                 if (SI[cur] < best) { best = SI[cur]; arrow = A_INSCLOSE; }
             }
+            if (local) {
+                if (0 < best) { best = 0; arrow = A_START; }
+                if (best < best_s) { best_s = best; best_r = r; best_t = tt; }
+            }
             S[cur] = best; A[cur] = arrow;
         }
     }
 
     /* traceback from the global end cell (last guide row, last target base) */
     int r = n - 1, tt = tEnd - 1;
-    int64_t endi = cell_index(g, n, r, tt);
+    if (local) { r = best_r; tt = best_t; }
+    int64_t endi = local && best_r < 0 ? -1 : cell_index(g, n, r, tt);
     int status = GBO_OK;
-    if (endi < 0 || S[endi] >= GBO_INF) status = GBO_UNREACHABLE;
+    if (local && best_r < 0) status = GBO_NO_ALIGNMENT;
+    else if (endi < 0 || S[endi] >= GBO_INF) status = GBO_UNREACHABLE;
     uint32_t nblk = 0, nM = 0, nX = 0, nI = 0, nD = 0;
     int64_t score2 = 0;
     if (status == GBO_OK) {
@@ -359,6 +378,7 @@ int gbo_align_qv(const uint8_t *q, uint32_t q_len, const uint8_t *t, uint32_t t_
         while (!(r == 0 && tt == tStart - 1)) {
             int64_t ci = cell_index(g, n, r, tt);
             if (ci < 0 || np >= cap) { status = GBO_UNREACHABLE; break; }
+            if (local && A[ci] == A_START) break;       /* the alignment begins behind this cell */
             if (state == 0) {
                 uint8_t a = A[ci];
                 if (a == A_DIAG) { path[np++] = 0; r--; tt--; }
@@ -380,7 +400,9 @@ int gbo_align_qv(const uint8_t *q, uint32_t q_len, const uint8_t *t, uint32_t t_
         if (status == GBO_OK) {
             /* ArrowPathToAlignment: merge consecutive diagonals into blocks; statistics
              * and rescoring as ComputeAlignmentStats (BlasrUtilsImpl.hpp:733-736). */
-            uint32_t qp = 0, tp = 0; int inblk = 0; int prev_op = 0;
+            /* (r, tt) is the cell the path begins behind: r query bases and tt - (tStart - 1) target bases of the
+             * region lie in front of the alignment (both 0 for a global alignment) */
+            uint32_t qp = (uint32_t)r, tp = (uint32_t)(tt - (tStart - 1)); int inblk = 0; int prev_op = 0;
             for (size_t k = np; k-- > 0;) {
                 uint8_t op = path[k];
                 if (op == 0) {
@@ -443,6 +465,33 @@ int gbo_full_dp_score(const uint8_t *q, uint32_t q_len, const uint8_t *t, uint32
         int32_t *tmp = prev; prev = cur; cur = tmp;
     }
     *score = prev[t_len];
+    free(prev); free(cur);
+    return GBO_OK;
+}
+
+/* Unbanded local alignment (Smith-Waterman in lower-is-better scores, linear gaps), score only: the cheapest
+ * cell of the whole matrix when every cell may also start an alignment at cost 0.  Property test: the banded
+ * LOCAL optimum equals it when the band holds the optimal local path. */
+int gbo_full_local_score(const uint8_t *q, uint32_t q_len, const uint8_t *t, uint32_t t_len,
+                         const gbo_params *P, int32_t *score)
+{
+    int32_t *prev = (int32_t *)calloc(t_len + 1, sizeof(int32_t));
+    int32_t *cur = (int32_t *)calloc(t_len + 1, sizeof(int32_t));
+    if (!prev || !cur) { free(prev); free(cur); return GBO_NOSPACE; }
+    int32_t best = 0;
+    for (uint32_t i = 1; i <= q_len; i++) {
+        cur[0] = 0;
+        int qc = gbo_code(q[i - 1]);
+        for (uint32_t j = 1; j <= t_len; j++) {
+            int m = prev[j - 1] + P->sub[qc][gbo_code(t[j - 1])];
+            int u = prev[j] + P->ins, l = cur[j - 1] + P->del;
+            int v = imin(m, imin(u, l));
+            cur[j] = v < 0 ? v : 0;
+            if (cur[j] < best) best = cur[j];
+        }
+        int32_t *tmp = prev; prev = cur; cur = tmp;
+    }
+    *score = best;
     free(prev); free(cur);
     return GBO_OK;
 }

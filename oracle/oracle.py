@@ -17,6 +17,8 @@ _ALT = os.environ.get("GBA_ORACLE_SO")
 
 MODE_LINEAR, MODE_AFFINE, MODE_KBAND = 0, 1, 2
 OK, EMPTY_GUIDE, BAD_GUIDE, UNREACHABLE, NOSPACE, END_OUT_OF_BAND = range(6)
+NO_ALIGNMENT = 9
+ALIGN_GLOBAL, ALIGN_LOCAL = 0, 1
 
 BLOCK_DT = np.dtype([("q_pos", "<u4"), ("t_pos", "<u4"), ("length", "<u4")])
 
@@ -30,7 +32,7 @@ class Params(C.Structure):
         ("stats_affine_open", C.c_int32), ("stats_affine_extend", C.c_int32),
         ("band", C.c_int32), ("max_band", C.c_int32),
         ("mode", C.c_int32), ("tie_break", C.c_int32),
-        ("kband_k", C.c_int32), ("stats_affine", C.c_int32),
+        ("kband_k", C.c_int32), ("stats_affine", C.c_int32), ("align_type", C.c_int32),
     ]
 
 
@@ -72,6 +74,7 @@ def lib():
         _lib.gbo_align_qv.restype = C.c_int
         _lib.gbo_guide_rows.restype = C.c_int
         _lib.gbo_full_dp_score.restype = C.c_int
+        _lib.gbo_full_local_score.restype = C.c_int
         _lib.gbo_align_batch.restype = C.c_int
         _lib.gbo_align_batch_mt.restype = C.c_int
         _lib.kbo_align.restype = C.c_int
@@ -84,7 +87,7 @@ def lib():
 
 def make_params(match=-5, mismatch=6, n_score=0, ins=5, dele=4, indel=5, band=10, max_band=250,
                 mode=MODE_LINEAR, tie_break=0, affine_open=10, affine_extend=0,
-                stats_affine=0, stats_affine_open=0, stats_affine_extend=0, kband_k=0, sub=None):
+                stats_affine=0, stats_affine_open=0, stats_affine_extend=0, kband_k=0, sub=None, align_type=0):
     p = Params()
     for a in range(5):
         for b in range(5):
@@ -101,6 +104,7 @@ def make_params(match=-5, mismatch=6, n_score=0, ins=5, dele=4, indel=5, band=10
     p.stats_affine_open, p.stats_affine_extend = stats_affine_open, stats_affine_extend
     p.band, p.max_band, p.mode, p.tie_break = band, max_band, mode, tie_break
     p.kband_k, p.stats_affine = kband_k, stats_affine
+    p.align_type = align_type
     return p
 
 
@@ -158,6 +162,16 @@ def full_dp_score(q, t, params):
                             t.ctypes.data_as(C.c_void_p), C.c_uint32(len(t)),
                             C.byref(params), C.byref(s))
     return s.value
+
+
+def full_local_score(q, t, params):
+    """Unbanded local optimum (Smith-Waterman in lower-is-better scores, linear gaps): the cheapest cell of the whole
+    matrix, 0 when nothing scores below zero."""
+    q, t = _u8(q), _u8(t)
+    out = C.c_int32(0)
+    lib().gbo_full_local_score(q.ctypes.data_as(C.c_void_p), C.c_uint32(len(q)), t.ctypes.data_as(C.c_void_p), C.c_uint32(len(t)),
+                               C.byref(params), C.byref(out))
+    return int(out.value)
 
 
 def align_batch(batch, params, first=0, count=None, blk_cap_per_pair=None):

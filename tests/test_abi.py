@@ -27,7 +27,7 @@ def test_exports_match_header():
 def test_version_and_strerror():
     from blasr_amd import _lib
     L = _lib.lib()
-    assert L.gba_version() == 370
+    assert L.gba_version() == 380
     assert L.gba_strerror(0) == b"ok"
     assert b"arena" in L.gba_strerror(_lib.E_NOSPACE)
     assert b"unknown" in L.gba_strerror(12345)
@@ -38,7 +38,7 @@ def test_struct_layouts():
     assert _lib.PAIR_RESULT_DT.itemsize == 88
     assert _lib.BLOCK_DT.itemsize == 12
     assert C.sizeof(_lib.Rescorer) == (25 + 5) * 4
-    assert C.sizeof(_lib.Scoring) == (25 + 14 + 1 + 2 * 30) * 4
+    assert C.sizeof(_lib.Scoring) == (25 + 14 + 1 + 2 * 30 + 1) * 4
     assert C.sizeof(_lib.Batch) == 8 + 9 * 8 + 3 * 8 + 8 + 8 + 8      # q_packed and its padding, q_profile
     assert C.sizeof(_lib.Results) == 72
 

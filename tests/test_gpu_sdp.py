@@ -221,16 +221,24 @@ def test_block_arena_too_small_and_long_reads(api, oracle, synth):
 
 
 def test_guided_align_from_sequences(api, oracle, synth):
-    """The composite the CCS path uses (chain of 6-mers, then a band of 12 around it) against the two
-    oracles run one after the other."""
-    from blasr_amd import refine
+    """The composite the CCS path uses (chain of 6-mers, then a band of 12 around it with the Local end rule) against the two
+    oracles run one after the other; reads with a stretch of unrelated sequence at one end, which the local rule leaves
+    off; the C++ mirror gives the same."""
+    import os
+    import subprocess
+    from blasr_amd import build, refine
     batch = synth.generate(4, read_len=1200, seed=61, p_ins=0.02, p_del=0.02, p_sub=0.01)
+    rng = np.random.default_rng(3)
     ctx = api.Context(0)
     try:
         params = refine.MappingParameters(sortRefinedAlignments=False, sdpMaxFragments=4096)
+        lines, got = ["4"], []
         for p in range(4):
             q, t, _ = synth.pair(batch, p)
             read, window = bytes(q), bytes(t)
+            # a 6-mer of the window repeated inside an unrelated read tail: the chain reaches into the tail, the alignment should not
+            tail = rng.choice(np.frombuffer(b"ACGT", np.uint8), 90).tobytes()
+            read = read + tail[:40] + window[-6:] + tail[40:]
             cands = [refine.AlignmentCandidate(tAlignedSeq=window)]
             refine.GuidedAlignFromSequences(read, cands, params, ctx)
             st, guide, _, _ = oracle.sdp_chain(read, window, oracle.make_sdp_params(k=6, max_fragments=4096))
@@ -238,10 +246,21 @@ def test_guided_align_from_sequences(api, oracle, synth):
             q0, t0 = int(guide[0]["q_pos"]), int(guide[0]["t_pos"])
             g = guide.copy(); g["q_pos"] -= np.uint32(q0); g["t_pos"] -= np.uint32(t0)
             ql, tl = int(g[-1]["q_pos"]) + int(g[-1]["length"]), int(g[-1]["t_pos"]) + int(g[-1]["length"])
-            er, eb = oracle.align(read[q0:q0 + ql], window[t0:t0 + tl], g, oracle.make_params(band=12))
+            er, eb = oracle.align(read[q0:q0 + ql], window[t0:t0 + tl], g, oracle.make_params(band=12, align_type=oracle.ALIGN_LOCAL))
             c = cands[0]
             assert (c.score, c.nMatch, c.nMismatch, c.nIns, c.nDel) == (er["score"], er["n_match"], er["n_mismatch"], er["n_ins"], er["n_del"])
-            assert len(c.blocks) == len(eb) and (c.blocks["length"] == eb["length"]).all()
-            assert c.nMatch > 0.9 * len(read)
+            assert len(c.blocks) == len(eb) and (c.blocks == eb).all()
+            assert c.nMatch > 0.9 * len(q)
+            assert c.qInterval[1] <= len(q) + 8          # the unrelated tail is not part of the alignment
+            lines.append("%s %s 0" % (read.decode(), window.decode()))
+            got.append(c)
+        exe = build.HOST_DEMO
+        assert os.path.exists(exe), "run python -m blasr_amd.build"
+        out = subprocess.run([exe, "ccs"], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        for row, c in zip(out.stdout.strip().split("\n"), got):
+            v = [int(x) for x in row.split()]
+            assert v[:6] == [c.status, c.score, c.nCells, c.qPos, c.tPos, len(c.blocks)]
+            assert v[6:] == [int(x) for b in c.blocks for x in b]
     finally:
         ctx.close()
