@@ -567,6 +567,26 @@ def main():
                 out["other_workloads"][key] = other_workload(torch, api, synth, _lib, name, pairs, 2, args.max_band, band)
             except Exception as e:          # a failure here must not cost the headline line
                 out["other_workloads"][key] = {"error": repr(e)[:300]}
+    if rank == 0 and world == 1 and not args.no_end_to_end and args.workload == "c2_10kb_linear":
+        # Reads in, filtered and scored alignments out: the C++ read-level harness (blasr_amd/host/read_harness.cpp) runs the
+        # candidates of every read through one from-sequences submit per batch and the reference's per-read steps behind
+        # the refine stage (sort, RemoveLowQualityAlignments, RemoveOverlappingAlignments, StoreMapQVs, -m 4 lines) on host
+        # threads while the next batch is on the GPU.  Seeding and clustering (where candidates come from) are not part of it.
+        import subprocess
+        from blasr_amd import build
+        out["end_to_end"] = {"what": "read_harness: candidates from the generator -> gba_submit from sequences (guides made on the device, refine, "
+                                     "pair results only) -> per read sort / filters / mapQV / m4 text; two contexts in turn, 4 batches back to back"}
+        env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+        for key, argv in (("c2_10kb_1_candidate", ["--reads", "122880", "--cands", "1", "--read-len", "10000", "--ref-len", str(synth.ECOLI_LEN), "--n-frac", "0", "--seed", "2000"]),
+                          ("c4_chr20_10_candidates", ["--reads", "16384", "--cands", "10", "--read-len", "10000", "--ref-len", str(synth.CHR20_LEN), "--n-frac", "0.01", "--seed", "4000"])):
+            try:
+                p = subprocess.run([build.READ_HARNESS] + argv + ["--batches", "4"], env=env, capture_output=True, text=True, timeout=600)
+                out["end_to_end"][key] = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else {"error": (p.stderr or p.stdout)[-300:]}
+            except Exception as e:
+                out["end_to_end"][key] = {"error": repr(e)[:300]}
+        e2 = out["end_to_end"].get("c2_10kb_1_candidate", {})
+        if "reads_per_sec" in e2:
+            out["end_to_end_reads_per_sec"] = e2["reads_per_sec"]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -46,11 +46,29 @@ def build_host_demo(force=False):
     return HOST_DEMO
 
 
+READ_HARNESS = os.path.join(_HERE, "host", "read_harness")
+
+
+def build_read_harness(force=False):
+    """The read-level harness (blasr_amd/host/read_harness.cpp): reads in, filtered and scored alignments out, over the C ABI;
+    links the synthetic generator for its input."""
+    from . import synth
+    src = os.path.join(_HERE, "host", "read_harness.cpp")
+    hdr = os.path.join(_HERE, "host", "gba_refine.hpp")
+    so = synth.build()
+    if force or _stale(READ_HARNESS, [src, hdr, HDR, LIBGBA, so]):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-o", READ_HARNESS, src,
+                               "-L" + _HERE, "-lgba", "-L" + os.path.dirname(so), "-lgbasynth",
+                               "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,$ORIGIN/../synth", "-Wl,-rpath,/opt/rocm/lib"])
+    return READ_HARNESS
+
+
 def build_all(force=False):
     from . import synth
     build_libgba(force)
     synth.build(force)
     build_host_demo(force)
+    build_read_harness(force)
 
 
 if __name__ == "__main__":
