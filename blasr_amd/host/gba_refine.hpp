@@ -37,6 +37,7 @@ struct MappingParameters {
     int guidedAlignBandSize = 10, bandSize = 16, maxBandSize = 250;
     bool useGuidedAlign = true, refineAlignments = true, sortRefinedAlignments = true;
     bool doGlobalAlignment = false;
+    bool refineBetweenAnchorsOnly = false;              // -rbao
     int maxScore = -200;
     int nCandidates = 10, nBest = 10;                   // :242-243
     float minPctSimilarity = 0;                         // :299
@@ -359,6 +360,89 @@ inline int SDPAlignCandidates(const std::string &read, std::vector<AlignmentCand
         const gba_block *src = blocks.data() + blk_off[i];
         c.qPos = src[0].q_pos; c.tPos = src[0].t_pos;
         for (uint32_t k = 0; k < n_blk[i]; k++) c.blocks.push_back(Block{src[k].q_pos - c.qPos, src[k].t_pos - c.tPos, src[k].length});
+    }
+    return GBA_OK;
+}
+
+// An exact match between read and genome that the seeding stage found: an anchor of a candidate (ChainedMatchPos in the
+// reference: q, t in read / genome coordinates on the forward strand, l bases).
+struct Anchor { uint32_t q, t, l; };
+
+// The -rbao branch of AlignIntervals (iblasr/BlasrAlignImpl.hpp:785-978): the guide of a candidate is its anchors with, between
+// two consecutive anchors that leave a gap in BOTH sequences, the chain SDPAlign finds inside that gap (:902-908).  All gaps of
+// all candidates of the read go through one gba_sdp call.  As in the reference an anchor is taken into the guide together with
+// the gap behind it: an anchor followed by no gap in the query or none in the target is left out (:877); the last anchor
+// always goes in (:938-949).  Blocks end up relative to the first one, qPos / tPos at its start (:951-964).  anchors[i]: those
+// of alignmentPtrs[i], in order (the strand flip of :828-851 is the caller's).  SDPAlign's Global flag for these calls is
+// libcpp's and unpinned: the chain is the best chain gba_sdp returns.
+inline int GuidesBetweenAnchors(const std::string &read, std::vector<AlignmentCandidate *> &alignmentPtrs,
+                                const std::vector<std::vector<Anchor>> &anchors, const MappingParameters &params, gba_ctx *ctx)
+{
+    struct Job { size_t c, k; uint32_t q0, t0, qGap, tGap; };
+    std::vector<Job> jobs;
+    std::string t_arena;
+    std::vector<uint64_t> t_base;
+    for (size_t ci = 0; ci < alignmentPtrs.size(); ci++) {
+        const AlignmentCandidate &c = *alignmentPtrs[ci];
+        t_base.push_back(t_arena.size());
+        t_arena += c.tAlignedSeq;
+        const std::vector<Anchor> &a = anchors[ci];
+        for (size_t k = 0; k + 1 < a.size(); k++) {
+            const int64_t tGap = (int64_t)a[k + 1].t - ((int64_t)a[k].t + a[k].l), qGap = (int64_t)a[k + 1].q - ((int64_t)a[k].q + a[k].l);
+            if (tGap > 0 && qGap > 0)
+                jobs.push_back(Job{ci, k, a[k].q + a[k].l - c.qAlignedSeqPos, a[k].t + a[k].l - c.tAlignedSeqPos, (uint32_t)qGap, (uint32_t)tGap});
+        }
+    }
+    std::vector<int32_t> status(jobs.size()), score(jobs.size());
+    std::vector<uint32_t> n_blk(jobs.size());
+    std::vector<uint64_t> blk_off(jobs.size());
+    std::vector<gba_block> blocks;
+    if (!jobs.empty()) {
+        const uint32_t n = (uint32_t)jobs.size();
+        std::vector<uint64_t> q_off(n), t_off(n);
+        std::vector<uint32_t> q_len(n), t_len(n);
+        uint64_t cap = n;
+        for (uint32_t x = 0; x < n; x++) {
+            const Job &j = jobs[x];
+            q_off[x] = (uint64_t)alignmentPtrs[j.c]->qAlignedSeqPos + j.q0; q_len[x] = j.qGap;
+            t_off[x] = t_base[j.c] + j.t0; t_len[x] = j.tGap;
+            cap += std::min(j.qGap, j.tGap);
+        }
+        if (t_arena.empty()) t_arena.push_back('N');
+        gba_batch b{};
+        b.n_pairs = n;
+        b.q_arena = (const uint8_t *)read.data(); b.q_off = q_off.data(); b.q_len = q_len.data(); b.q_arena_bytes = read.size();
+        b.t_arena = (const uint8_t *)t_arena.data(); b.t_off = t_off.data(); b.t_len = t_len.data(); b.t_arena_bytes = t_arena.size();
+        gba_sdp_params sp{params.sdpTupleSize, params.sdpIns, params.sdpDel, -params.match, params.sdpMaxFragments};
+        blocks.resize(cap);
+        gba_guides g{status.data(), score.data(), n_blk.data(), blk_off.data(), blocks.data(), blocks.size(), 0};
+        const int rc = gba_sdp(ctx, &b, &sp, &g);
+        if (rc != GBA_OK) return rc;
+    }
+    size_t x = 0;
+    for (size_t ci = 0; ci < alignmentPtrs.size(); ci++) {
+        AlignmentCandidate &c = *alignmentPtrs[ci];
+        const std::vector<Anchor> &a = anchors[ci];
+        std::vector<Block> out;
+        for (size_t k = 0; k + 1 < a.size(); k++) {
+            if (x < jobs.size() && jobs[x].c == ci && jobs[x].k == k) {
+                out.push_back(Block{a[k].q - c.qAlignedSeqPos, a[k].t - c.tAlignedSeqPos, a[k].l});
+                if (status[x] == GBA_PAIR_OK)
+                    for (uint32_t i = 0; i < n_blk[x]; i++) {
+                        const gba_block &gb = blocks[blk_off[x] + i];
+                        out.push_back(Block{gb.q_pos + jobs[x].q0, gb.t_pos + jobs[x].t0, gb.length});      // :921-923
+                    }
+                x++;
+            }
+        }
+        if (!a.empty()) out.push_back(Block{a.back().q - c.qAlignedSeqPos, a.back().t - c.tAlignedSeqPos, a.back().l});
+        c.qPos = c.tPos = 0;
+        if (!out.empty()) {
+            c.qPos = out[0].qPos; c.tPos = out[0].tPos;
+            for (Block &bk : out) { bk.qPos -= c.qPos; bk.tPos -= c.tPos; }
+        }
+        c.blocks.swap(out);
+        c.status = c.blocks.empty() ? GBA_PAIR_EMPTY_GUIDE : GBA_PAIR_OK;
     }
     return GBA_OK;
 }

@@ -10,6 +10,8 @@
 //   sdp      the guides come from the device first (SDPAlignCandidates: the blocks of the input are ignored), then the batch
 //   ccs      GuidedAlignFromSequences on each (read, candidate): guides from 6-mers, band 12, the Local end rule (the blocks of
 //            the input are ignored)
+//   rbao     every candidate line carries, behind its blocks, "nanchors (q t l)*": the guide comes from GuidesBetweenAnchors (the
+//            blocks of the input are ignored), then the batch
 //   fused    SDPAlign and RefineAlignment in one submit (AlignAndRefineCandidates; the blocks of the input are ignored)
 //   intervals  run without a block arena and print per candidate: status score nBlocks qStart qEnd tStart tEnd
 //   qv       every candidate line carries five more strings behind its blocks (insertionQV deletionQV deletionTag substitutionQV
@@ -113,11 +115,19 @@ int main(int argc, char **argv)
     std::vector<std::string> reads(n);
     std::vector<gba::AlignmentCandidate> cands(n);
     std::vector<gba::QualityValues> qvs;
+    std::vector<std::vector<gba::Anchor>> anchor_sets;
     for (size_t i = 0; i < n; i++) {
         size_t nb;
         std::cin >> reads[i] >> cands[i].tAlignedSeq >> nb;
         cands[i].blocks.resize(nb);
         for (auto &b : cands[i].blocks) std::cin >> b.qPos >> b.tPos >> b.length;
+        if (mode == "rbao") {
+            size_t na;
+            std::cin >> na;
+            std::vector<gba::Anchor> a(na);
+            for (auto &m : a) std::cin >> m.q >> m.t >> m.l;
+            anchor_sets.push_back(a);
+        }
         if (mode == "qv") {
             gba::QualityValues q;
             std::cin >> q.insertionQV >> q.deletionQV >> q.deletionTag >> q.substitutionQV >> q.substitutionTag;
@@ -236,6 +246,14 @@ int main(int argc, char **argv)
             rc = gba::AlignAndRefineCandidates(reads[i], one, params, ctx);
         }
     } else {
+        if (mode == "rbao") {
+            for (size_t i = 0; i < n && rc == GBA_OK; i++) {
+                std::vector<gba::AlignmentCandidate *> one{&cands[i]};
+                std::vector<std::vector<gba::Anchor>> a{anchor_sets[i]};
+                rc = gba::GuidesBetweenAnchors(reads[i], one, a, params, ctx);
+            }
+            if (rc != GBA_OK) { std::fprintf(stderr, "GuidesBetweenAnchors: %s\n", gba_strerror(rc)); return 1; }
+        }
         if (sdp) {
             for (size_t i = 0; i < n && rc == GBA_OK; i++) {
                 std::vector<gba::AlignmentCandidate *> one{&cands[i]};

@@ -49,6 +49,7 @@ class MappingParameters:
     sdpBypassThreshold: float = 1000000.0   # :340 (0.75 in the -sdpbypass preset, :721)
     scoreMatrix: Optional[list] = None     # 5x5, -scoreMatrix (Blasr.cpp:922-937)
     ignoreQualities: bool = True           # :285; -useQuality turns it off
+    refineBetweenAnchorsOnly: bool = False  # -rbao (iblasr/RegisterBlasrOptions.h; MappingParameters.h)
 
 
 @dataclass
@@ -288,11 +289,19 @@ def GuidesFromAnchorsOrSDP(read: bytes, cands: List[AlignmentCandidate], anchors
     coordinates) cover at least params.sdpBypassThreshold of the subread they are the guide
     themselves (:992-1004: block = anchor - aligned-sequence position), otherwise the guide comes
     from SDPAlign over the candidate's two sequences (:980-987).  The default threshold (1e6)
-    sends every candidate to SDPAlign.  The -rbao variant (SDP between consecutive anchors only,
-    :785-978) is not mirrored."""
+    sends every candidate to SDPAlign.  With params.refineBetweenAnchorsOnly (-rbao) the candidates that
+    need SDP get it between their anchors only (GuidesBetweenAnchors, :785-978)."""
     n_sub = subreadLength if subreadLength is not None else len(read)
+    if params.refineBetweenAnchorsOnly:
+        sparse = [(c, a) for c, a in zip(cands, anchors) if not (n_sub and sum(int(m[2]) for m in a) / n_sub >= params.sdpBypassThreshold)]
+        dense = [(c, a) for c, a in zip(cands, anchors) if n_sub and sum(int(m[2]) for m in a) / n_sub >= params.sdpBypassThreshold]
+        if sparse:
+            GuidesBetweenAnchors(read, [c for c, _ in sparse], [a for _, a in sparse], params, ctx)
+        cands_, anchors_ = [c for c, _ in dense], [a for _, a in dense]
+    else:
+        cands_, anchors_ = cands, anchors
     todo = []
-    for c, a in zip(cands, anchors):
+    for c, a in zip(cands_, anchors_):
         covered = sum(int(m[2]) for m in a)
         if n_sub and covered / n_sub >= params.sdpBypassThreshold:
             b = np.zeros(len(a), dtype=BLOCK_DT)
@@ -304,6 +313,63 @@ def GuidesFromAnchorsOrSDP(read: bytes, cands: List[AlignmentCandidate], anchors
             todo.append(c)
     if todo:
         SDPAlignCandidates(read, todo, params, ctx)
+    return cands
+
+
+def GuidesBetweenAnchors(read: bytes, cands: List[AlignmentCandidate], anchors: List[list], params: MappingParameters, ctx):
+    """The -rbao branch of AlignIntervals (/root/reference/iblasr/BlasrAlignImpl.hpp:785-978): the guide of a candidate is its
+    anchors (exact matches (q, t, l) in read / genome coordinates, in order, forward strand; the strand flip of :828-851 is the
+    caller's) with, between two consecutive anchors that leave a gap in BOTH sequences, the chain SDPAlign finds inside that
+    gap (:902-908: the sub-sequences between the anchors, params.sdpTupleSize, sdpIns, sdpDel).  All gaps of all candidates
+    go through one gba_sdp call.  As in the reference an anchor is taken into the guide together with the gap behind it:
+    an anchor that is followed by no gap in the query or none in the target (tGap <= 0 or qGap <= 0, :877) is left out;
+    the last anchor always goes in (:938-949).  Blocks end up relative to the first one, qPos / tPos at its start (:951-964).
+    SDPAlign's Global flag for these calls is libcpp's and unpinned: the chain is the same best chain gba_sdp returns."""
+    jobs = []          # (candidate index, anchor index, q start, t start, q gap, t gap) in read / window coordinates
+    for ci, (c, a) in enumerate(zip(cands, anchors)):
+        m = [(int(q) - c.qAlignedSeqPos, int(t) - c.tAlignedSeqPos, int(l)) for q, t, l in a]      # relative to the aligned sequences (:822-827)
+        for k in range(len(m) - 1):
+            t_gap = m[k + 1][1] - (m[k][1] + m[k][2])
+            q_gap = m[k + 1][0] - (m[k][0] + m[k][2])
+            if t_gap > 0 and q_gap > 0:
+                jobs.append((ci, k, m[k][0] + m[k][2], m[k][1] + m[k][2], q_gap, t_gap))
+    found = {}
+    if jobs:
+        # one batch: the query arena is the read, the target arena the candidates' windows one after the other
+        t_base, acc = [], 0
+        for c in cands:
+            t_base.append(acc); acc += len(c.tAlignedSeq)
+        batch = {"n_pairs": len(jobs), "q_arena": np.frombuffer(read, dtype=np.uint8),
+                 "t_arena": np.frombuffer(b"".join(c.tAlignedSeq for c in cands) or b"N", dtype=np.uint8),
+                 "q_off": np.array([cands[j[0]].qAlignedSeqPos + j[2] for j in jobs], np.uint64), "q_len": np.array([j[4] for j in jobs], np.uint32),
+                 "t_off": np.array([t_base[j[0]] + j[3] for j in jobs], np.uint64), "t_len": np.array([j[5] for j in jobs], np.uint32)}
+        sp = make_sdp_params(tuple_size=params.sdpTupleSize, ins=params.sdpIns, dele=params.sdpDel, match=-params.match,
+                             max_fragments=params.sdpMaxFragments)
+        status, score, n_blk, off, blocks, rc = ctx.sdp_host(batch, sp, blocks_capacity=int(sum(min(j[4], j[5]) for j in jobs)) + len(jobs))
+        for x, j in enumerate(jobs):
+            if int(status[x]) == _lib.PAIR_OK and int(n_blk[x]):
+                b = blocks[int(off[x]):int(off[x]) + int(n_blk[x])].copy()
+                b["q_pos"] += np.uint32(j[2]); b["t_pos"] += np.uint32(j[3])          # :921-923
+                found[(j[0], j[1])] = b
+    for ci, (c, a) in enumerate(zip(cands, anchors)):
+        m = [(int(q) - c.qAlignedSeqPos, int(t) - c.tAlignedSeqPos, int(l)) for q, t, l in a]
+        parts = []
+        for k in range(len(m) - 1):
+            t_gap = m[k + 1][1] - (m[k][1] + m[k][2])
+            q_gap = m[k + 1][0] - (m[k][0] + m[k][2])
+            if t_gap > 0 and q_gap > 0:
+                parts.append(np.array([m[k]], dtype=BLOCK_DT))
+                if (ci, k) in found:
+                    parts.append(found[(ci, k)])
+        if m:
+            parts.append(np.array([m[-1]], dtype=BLOCK_DT))
+        b = np.concatenate(parts) if parts else np.zeros(0, dtype=BLOCK_DT)
+        c.qPos = c.tPos = 0
+        if len(b):
+            c.qPos, c.tPos = int(b[0]["q_pos"]), int(b[0]["t_pos"])
+            b["q_pos"] -= np.uint32(c.qPos); b["t_pos"] -= np.uint32(c.tPos)
+        c.blocks = b
+        c.status = _lib.PAIR_OK if len(b) else _lib.PAIR_EMPTY_GUIDE
     return cands
 
 

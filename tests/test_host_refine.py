@@ -280,3 +280,58 @@ def test_cpp_worker_pool_equals_one_context(synth):
     assert f[0] == "ok" and int(f[1]) == 96 and int(f[2]) > 96
     staged, total = [int(x) for x in f[3:6]], int(f[6])
     assert sum(staged) == total and max(staged) < 0.5 * total
+
+
+@pytest.mark.gpu
+def test_guides_between_anchors(oracle, synth):
+    """The -rbao guide (refine.GuidesBetweenAnchors, gba::GuidesBetweenAnchors: /root/reference/iblasr/BlasrAlignImpl.hpp:785-978):
+    anchors plus the chain found inside every gap between two of them, against the same composition made from the SDP
+    oracle's chains; an anchor without a two-sided gap behind it is left out as the reference leaves it out; the guide then
+    drives the refine stage; the C++ mirror gives the same candidates."""
+    from blasr_amd import api, build, refine
+    import difflib
+    batch = synth.generate(5, read_len=2500, len_jitter=500, seed=404)
+    ctx = api.Context(0)
+    params = refine.MappingParameters(sortRefinedAlignments=False, refineBetweenAnchorsOnly=True)
+    try:
+        lines, got = ["5"], []
+        for p in range(5):
+            q, t, _ = synth.pair(batch, p)
+            read, window = bytes(q), bytes(t)
+            # anchors: long exact matches in order, as seeding would leave them (every third one kept: wide gaps between them)
+            mb = [m for m in difflib.SequenceMatcher(None, read, window, autojunk=False).get_matching_blocks() if m.size >= 14][::3]
+            anchors = [(m.a, m.b, m.size) for m in mb]
+            if p == 1 and len(anchors) > 3:           # an anchor that touches the next one in the target: no gap on that side
+                a2 = anchors[2]
+                anchors[1] = (anchors[1][0], anchors[1][1], a2[1] - anchors[1][1]) if a2[1] - anchors[1][1] <= a2[0] - anchors[1][0] else anchors[1]
+            c = refine.AlignmentCandidate(tAlignedSeq=window)
+            refine.GuidesFromAnchorsOrSDP(read, [c], [anchors], params, ctx)
+            # the same from the oracle's chains
+            want = []
+            for k in range(len(anchors) - 1):
+                qa, ta, la = anchors[k]
+                q_gap, t_gap = anchors[k + 1][0] - (qa + la), anchors[k + 1][1] - (ta + la)
+                if q_gap > 0 and t_gap > 0:
+                    want.append((qa, ta, la))
+                    st, g, _, _ = oracle.sdp_chain(read[qa + la:qa + la + q_gap], window[ta + la:ta + la + t_gap], oracle.make_sdp_params())
+                    if st == 0:
+                        want += [(int(b["q_pos"]) + qa + la, int(b["t_pos"]) + ta + la, int(b["length"])) for b in g]
+            want.append(anchors[-1])
+            assert c.status == 0 and (c.qPos, c.tPos) == (want[0][0], want[0][1])
+            assert [(int(b["q_pos"]) + c.qPos, int(b["t_pos"]) + c.tPos, int(b["length"])) for b in c.blocks] == want, p
+            assert len(want) > len([1 for k in range(len(anchors))])       # the gaps did contribute blocks
+            guide = c.blocks.copy()
+            refine.RefineAlignments(read, [c], params, ctx)
+            ql, tl = int(guide[-1]["q_pos"] + guide[-1]["length"]), int(guide[-1]["t_pos"] + guide[-1]["length"])
+            er, eb = oracle.align(read[want[0][0]:want[0][0] + ql], window[want[0][1]:want[0][1] + tl], guide, oracle.make_params())
+            assert c.status == 0 and (c.score, c.nCells, len(c.blocks)) == (er["score"], er["ncells"], er["n_blk"])
+            got.append(c)
+            lines.append("%s %s 0 %d %s" % (read.decode(), window.decode(), len(anchors), " ".join("%d %d %d" % a for a in anchors)))
+        out = subprocess.run([build.HOST_DEMO, "rbao"], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        for row, c in zip(out.stdout.strip().split("\n"), got):
+            v = [int(x) for x in row.split()]
+            assert v[:6] == [c.status, c.score, c.nCells, c.qPos, c.tPos, len(c.blocks)]
+            assert v[6:] == [int(x) for b in c.blocks for x in b]
+    finally:
+        ctx.close()
