@@ -298,9 +298,13 @@ class Context:
             if batch.get(k) is not None:
                 keep[k] = np.ascontiguousarray(batch[k], dtype=np.uint8)
         ta, trc = keep.get("t_arena"), keep.get("t_rc")
+        packed = bool(batch.get("q_packed"))
+        if packed and keep["q_arena"].size < (int(batch["q_bases"]) + 15) // 16 * 4:
+            raise ValueError("packed q_arena shorter than ((q_bases + 15) / 16) * 4 bytes")
         b = Batch(n, _ptr(keep["q_arena"]), _ptr(keep["q_off"]), _ptr(keep["q_len"]), _ptr(ta) if ta is not None else None,
-                  _ptr(keep["t_off"]), _ptr(keep["t_len"]), None, None, None, keep["q_arena"].size, ta.size if ta is not None else 0, 0,
-                  _ptr(trc) if trc is not None else None)
+                  _ptr(keep["t_off"]), _ptr(keep["t_len"]), None, None, None,
+                  int(batch["q_bases"]) if packed else keep["q_arena"].size, ta.size if ta is not None else 0, 0,
+                  _ptr(trc) if trc is not None else None, 1 if packed else 0)
         status = np.zeros(n, np.int32); score = np.zeros(n, np.int32); n_blk = np.zeros(n, np.uint32); off = np.zeros(n, np.uint64)
         blocks = np.zeros(int(blocks_capacity), dtype=BLOCK_DT)
         r = Guides(_ptr(status), _ptr(score), _ptr(n_blk), _ptr(off), _ptr(blocks), int(blocks_capacity), 0)
@@ -324,10 +328,11 @@ class Context:
              "blocks": torch.zeros((int(blocks_capacity), 3), dtype=torch.int32, device=dev)}
         ta = dbatch.get("t_arena")
         trc = dbatch.get("t_rc")
+        packed = bool(dbatch.get("q_packed"))
         b = Batch(n, dbatch["q_arena"].data_ptr(), dbatch["q_off"].data_ptr(), dbatch["q_len"].data_ptr(),
                   ta.data_ptr() if ta is not None else None, dbatch["t_off"].data_ptr(), dbatch["t_len"].data_ptr(),
-                  None, None, None, dbatch["q_arena"].numel(), ta.numel() if ta is not None else 0, 0,
-                  trc.data_ptr() if trc is not None else None)
+                  None, None, None, int(dbatch["q_bases"]) if packed else dbatch["q_arena"].numel(), ta.numel() if ta is not None else 0, 0,
+                  trc.data_ptr() if trc is not None else None, 1 if packed else 0)
         r = Guides(g["status"].data_ptr(), g["chain_score"].data_ptr(), g["n_blk"].data_ptr(), g["blk_off"].data_ptr(),
                    g["blocks"].data_ptr(), int(blocks_capacity), 0)
         g["rc"] = self._check(self._L.gba_sdp_device(self._h, C.byref(b), C.byref(params), C.byref(r)), allow=(_lib.E_NOSPACE,))
@@ -349,14 +354,17 @@ class Context:
         ta = dbatch.get("t_arena")
         trc = dbatch.get("t_rc")
         gb = dbatch.get("blocks")         # absent: guides made on the device (set_guide_producer)
+        packed = bool(dbatch.get("q_packed"))     # reads 2 bits per base, q_bases of them (pack_reads_2bit)
+        if packed and dbatch["q_arena"].numel() < (int(dbatch["q_bases"]) + 15) // 16 * 4:
+            raise ValueError("packed q_arena shorter than ((q_bases + 15) / 16) * 4 bytes")
         b = Batch(n, dbatch["q_arena"].data_ptr(), dbatch["q_off"].data_ptr(), dbatch["q_len"].data_ptr(),
                   ta.data_ptr() if ta is not None else None, dbatch["t_off"].data_ptr(), dbatch["t_len"].data_ptr(),
                   gb.data_ptr() if gb is not None else None, dbatch["blk_off"].data_ptr() if gb is not None else None,
                   dbatch["n_blk"].data_ptr() if gb is not None else None,
-                  dbatch["q_arena"].numel(), ta.numel() if ta is not None else 0, gb.shape[0] if gb is not None else 0,
-                  trc.data_ptr() if trc is not None else None)
+                  int(dbatch["q_bases"]) if packed else dbatch["q_arena"].numel(), ta.numel() if ta is not None else 0,
+                  gb.shape[0] if gb is not None else 0, trc.data_ptr() if trc is not None else None, 1 if packed else 0)
         if dbatch.get("q_profile") is not None:       # int16 tensor, 11 per base of q_arena
-            assert dbatch["q_profile"].element_size() == 2 and dbatch["q_profile"].numel() == 11 * dbatch["q_arena"].numel()
+            assert dbatch["q_profile"].element_size() == 2 and dbatch["q_profile"].numel() == 11 * int(b.q_arena_bytes)
             b.q_profile = dbatch["q_profile"].data_ptr()
         assert out_pairs.numel() * out_pairs.element_size() >= n * PAIR_RESULT_DT.itemsize
         r = Results(out_pairs.data_ptr(), out_blocks.data_ptr() if out_blocks is not None else None,
@@ -499,4 +507,6 @@ def to_device(batch, device="cuda:0"):
         d["blocks"] = torch.from_numpy(blk.view(np.uint32).reshape(-1, 3).view(np.int32)).to(device)
     if batch.get("q_profile") is not None:
         d["q_profile"] = torch.from_numpy(np.ascontiguousarray(batch["q_profile"], dtype=np.int16)).to(device)
+    if batch.get("q_packed"):
+        d["q_packed"], d["q_bases"] = 1, int(batch["q_bases"])
     return d

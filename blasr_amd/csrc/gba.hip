@@ -95,6 +95,10 @@ struct Dev {                  // per-batch device state, SoA per pair
     const gba_block *blocks;
     const int32_t *guide_status;   // guides made by the library itself: why a pair has none (null: the caller's guides)
     const int16_t *prof;           // costs of a quality-value scorer, 11 per byte of q_arena (null: matrix, ins, del)
+    // Packed sources, 2 bits per base (base x = bits 2 (x & 15) .. of dword x >> 4; A, C, G, T = 0 .. 3):
+    const uint32_t *q_pk;          // non-null: the query arena is packed (gba_batch.q_packed) and q_arena is not read
+    const uint32_t *ref_pk, *ref_mask;   // non-null: the targets are windows of the resident reference, kept packed with one mask
+                                   // bit per base (bit x & 31 of dword x >> 5) for the letters outside ACGT; t_arena is not read
     // per pair
     int32_t *status;
     uint32_t *qS, *tS, *Q, *T, *rows, *cols, *wcap, *span, *lo_last, *cls, *order, *recdw;
@@ -141,6 +145,15 @@ __device__ __forceinline__ uint32_t base_code(uint8_t c)
     // A/a C/c G/g T/t -> 0..3, everything else N = 4
     uint32_t u = c & 0xdfu;
     return u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : 4u;
+}
+
+// code 0 .. 3 of base `pos` of a packed array
+__device__ __forceinline__ uint32_t packed_code(const uint32_t *pk, uint64_t pos) { return (pk[pos >> 4] >> (2u * (uint32_t)(pos & 15u))) & 3u; }
+__device__ __forceinline__ uint32_t mask_bit(const uint32_t *mk, uint64_t pos) { return (mk[pos >> 5] >> (uint32_t)(pos & 31u)) & 1u; }
+// code 0 .. 4 of the query base at arena position `pos`: letters, or a packed arena
+__device__ __forceinline__ uint32_t query_code(const uint8_t *q_arena, const uint32_t *q_pk, uint64_t pos)
+{
+    return q_pk ? packed_code(q_pk, pos) : base_code(q_arena[pos]);
 }
 
 __device__ __forceinline__ uint64_t align16(uint64_t x) { return (x + 15) & ~uint64_t(15); }
@@ -297,6 +310,27 @@ __global__ __launch_bounds__(256) void k_pack(Dev d)
     const uint32_t T = d.T[p];
     uint8_t *tc = d.tcodes + tc_offset(d, p);
     const bool rc = d.t_rc != nullptr && d.t_rc[p] != 0;
+    if (d.ref_pk) {
+        // a window of the packed reference: column j is base t_off + tS + j - 1 of it, or, on the reverse strand, base
+        // t_off + t_len - tS - j complemented; a masked base (a letter outside ACGT) is N
+        const uint64_t first = d.t_off[p] + (rc ? (uint64_t)d.t_len[p] - d.tS[p] : (uint64_t)d.tS[p]);
+        for (uint32_t j0 = 4 * threadIdx.x; j0 <= T + 16; j0 += 4 * blockDim.x) {
+            uint32_t outw = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const uint32_t j = j0 + x;
+                uint32_t code = 4u;
+                if (j >= 1 && j <= T) {
+                    const uint64_t g = rc ? first - j : first + j - 1;
+                    const uint32_t f = packed_code(d.ref_pk, g);
+                    code = mask_bit(d.ref_mask, g) ? 4u : rc ? 3u - f : f;
+                }
+                outw |= (code + 1u) << (8 * x);
+            }
+            *(uint32_t *)(tc + j0) = outw;
+        }
+        return;
+    }
     // forward: column j is slice byte tS + j - 1; reverse complement: the slice read backwards from
     // its last byte, bases complemented (A<->T, C<->G, N stays)
     const uint8_t *t = d.t_arena + d.t_off[p] + (rc ? (uint64_t)d.t_len[p] - d.tS[p] : (uint64_t)d.tS[p]);
@@ -395,7 +429,7 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
     const uint32_t Q = d.Q[p], T = d.T[p], tS = d.tS[p], qS = d.qS[p];
     uint32_t *g = d.stream + d.word_off[p];
     const uint32_t wcap = d.wcap[p];
-    const uint8_t *qa = d.q_arena + d.q_off[p] + qS;        // query base of DP row r is qa[r - 1]
+    const uint64_t qa0 = d.q_off[p] + qS;                   // query base of DP row r is base qa0 + r - 1 of the query arena
     const uint8_t *tc = d.tcodes + tc_offset(d, p);
     const uint32_t B = (uint32_t)(guided ? min(band, max_band) : kband_k);
     const uint32_t wfirst = max((uint32_t)max_band, B);
@@ -474,7 +508,7 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
             span = max(span, dl + W);
             recdw += 1u + (mode == GBA_MODE_AFFINE ? (W + 3u) >> 2 : (W + 15u) >> 4);
             if (dl > 1023u || W > 1023u) wide = true;
-            uint32_t word = (W & ROW_W_MASK) | ((r > 0u ? base_code(qa[r - 1u]) : 4u) << 10) | ((dl & 1023u) << 13);
+            uint32_t word = (W & ROW_W_MASK) | ((r > 0u ? query_code(d.q_arena, d.q_pk, qa0 + r - 1u) : 4u) << 10) | ((dl & 1023u) << 13);
             if (nnew > 0u) {
                 const uint32_t t4 = *(const u32u1 *)(tc + cnew);           // codes of columns cnew .. cnew + 3 (padding behind the last one)
                 word |= (t4 & 7u) << 23;
@@ -1964,23 +1998,21 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
 }
 
 // ---------------------------------------------------------------- results
-// Reads that travelled 2 bits per base (gba_batch.q_packed) are spelt out as letters where the kernels expect them:
-// one thread per 16 bases (one packed dword in, 16 letters out).
-__global__ __launch_bounds__(256) void k_unpack2(const uint32_t *pk, u32x4 *out, uint64_t first16, uint64_t n16)
+// The reference as the library keeps it: 2 bits per base and one mask bit per base for every letter outside ACGT (upper or
+// lower case).  One thread per 32 letters of a chunk that starts at base `first` (a multiple of 32) of the reference.
+__global__ __launch_bounds__(256) void k_ref_pack(const uint8_t *letters, uint64_t n, uint64_t first, uint32_t *pk, uint32_t *mask)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n16) return;
-    const uint32_t w = pk[first16 + i];
-    u32x4 o;
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const uint32_t byte = (w >> (8 * b)) & 255u;
-        uint32_t v = 0;
-#pragma unroll
-        for (int x = 0; x < 4; x++) v |= ((0x54474341u >> (8 * ((byte >> (2 * x)) & 3u))) & 255u) << (8 * x);     // "ACGT"[code]
-        o[b] = v;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;       // 32-base group of the chunk
+    if (i * 32 >= n) return;
+    uint32_t lo = 0, hi = 0, m = 0;
+    for (uint32_t x = 0; x < 32u && i * 32 + x < n; x++) {
+        const uint32_t c = base_code(letters[i * 32 + x]);
+        const uint32_t v = c & 3u;                                       // N packs as A, and is masked
+        if (x < 16u) lo |= (c < 4u ? v : 0u) << (2u * x); else hi |= (c < 4u ? v : 0u) << (2u * (x - 16u));
+        m |= (c >= 4u ? 1u : 0u) << x;
     }
-    out[first16 + i] = o;
+    const uint64_t g = first / 32 + i;
+    pk[2 * g] = lo; pk[2 * g + 1] = hi; mask[g] = m;
 }
 
 __global__ void k_results_init(Dev d, gba_pair_result *res)
@@ -2112,11 +2144,11 @@ __global__ __launch_bounds__(64) void k_cigar(Dev d, uint32_t flags, const uint6
     const bool seqm = (flags & GBA_CIGAR_SEQ_MATCH) != 0, adj = (flags & GBA_CIGAR_ADJACENT_INDELS) != 0;
     if (!WRITE && seqm) {
         // a row's record is at least two dwords, so Q + 8 bytes fit the pair's records
-        const uint8_t *q = d.q_arena + d.q_off[p] + d.qS[p];
+        const uint64_t q0 = d.q_off[p] + d.qS[p];
         for (uint32_t x0 = 4 * lane; x0 < Q + 8; x0 += 256) {
             uint32_t w = 0;
 #pragma unroll
-            for (int x = 0; x < 4; x++) w |= (x0 + x < Q ? base_code(q[x0 + x]) + 1u : 6u) << (8 * x);   // past the end: equal to no target code
+            for (int x = 0; x < 4; x++) w |= (x0 + x < Q ? query_code(d.q_arena, d.q_pk, q0 + x0 + x) + 1u : 6u) << (8 * x);   // past the end: equal to no target code
             *(uint32_t *)(qc + x0) = w;
         }
         __syncthreads();
@@ -2241,6 +2273,7 @@ struct SdpConst {
 
 // What k_sdp_match needs of a batch besides its constants (all device pointers).
 struct SdpIn {
+    const uint32_t *q_pk, *ref_pk, *ref_mask;      // packed sources (see Dev); null: letters
     const uint8_t *q_arena, *t_arena, *t_rc;
     uint64_t q_arena_bytes, t_arena_bytes;
     const uint64_t *q_off, *t_off;
@@ -2273,6 +2306,29 @@ __device__ __forceinline__ uint32_t window16(const uint32_t *pk, uint32_t pos)
     const uint32_t w = pos >> 4, b = (pos & 15u) * 2u;
     const uint64_t v = (uint64_t)pk[w] | (uint64_t)pk[w + 1] << 32;
     return (uint32_t)(v >> b);
+}
+// the same for a packed array in global memory indexed by a 64-bit base position (a dword of padding follows the array)
+__device__ __forceinline__ uint32_t gwindow16(const uint32_t *pk, uint64_t pos, uint64_t ndw)
+{
+    const uint64_t w = pos >> 4;
+    const uint32_t b = (uint32_t)(pos & 15u) * 2u;
+    const uint64_t v = (uint64_t)pk[w] | (uint64_t)(w + 1 < ndw ? pk[w + 1] : 0u) << 32;     // ndw: dwords of the array
+    return (uint32_t)(v >> b);
+}
+// 16 mask bits (one per base) starting at base `pos`, spread to the "01 per marked base" form of the packed marks
+__device__ __forceinline__ uint32_t gmarks16(const uint32_t *mk, uint64_t pos)
+{
+    const uint64_t w = pos >> 5;
+    const uint32_t b = (uint32_t)(pos & 31u);
+    uint32_t m = (uint32_t)(((uint64_t)mk[w] | (uint64_t)mk[w + 1] << 32) >> b) & 0xffffu;
+    m = (m | m << 8) & 0x00ff00ffu; m = (m | m << 4) & 0x0f0f0f0fu; m = (m | m << 2) & 0x33333333u; m = (m | m << 1) & 0x55555555u;
+    return m;
+}
+// the sixteen 2-bit fields of a dword in reverse order
+__device__ __forceinline__ uint32_t reverse_fields(uint32_t v)
+{
+    v = __builtin_bitreverse32(v);
+    return ((v & 0x55555555u) << 1) | ((v >> 1) & 0x55555555u);
 }
 
 // Matches of one pair: its fragments (query start << 16 | target start, length) go to frags + pair * cap in no
@@ -2310,7 +2366,30 @@ __global__ __launch_bounds__(SDP_THREADS) void k_sdp_match(SdpIn in, SdpConst sc
             const uint8_t *seq = isq ? qa : ta;
             const bool back = !isq && rc;
             uint32_t bases = 0, marks = 0x55555555u;
-            if (ww * 16u < len) {
+            const uint32_t *pk = isq ? in.q_pk : in.ref_pk;
+            if (pk && ww * 16u < len) {
+                // a packed source: sixteen bases are one funnel shift (read backwards: the sixteen bases that end where the
+                // word begins, fields reversed and complemented); what lies beyond the sequence's end is marked
+                const uint32_t x0 = ww * 16u, v = len - x0 < 16u ? len - x0 : 16u;
+                const uint64_t base0 = isq ? in.q_off[p] : in.t_off[p];
+                const uint64_t ndw = ((isq ? in.q_arena_bytes : in.t_arena_bytes) + 15u) >> 4;
+                uint32_t mk = 0;
+                if (!back) {
+                    bases = gwindow16(pk, base0 + x0, ndw);
+                    if (!isq) mk = gmarks16(in.ref_mask, base0 + x0);
+                } else {
+                    // bases len - 1 - x0 - x, x = 0 .. 15: the forward stretch [len - x0 - 16, len - x0) reversed; near the
+                    // window's start the stretch begins before the window (v < 16): shift what is outside away
+                    const uint64_t hi = base0 + len - x0;                       // one past the last forward base of the word
+                    const uint64_t lo16 = hi >= 16u ? hi - 16u : 0u;
+                    const uint32_t miss = (uint32_t)(16u - (hi - lo16));        // bases in front of the array's start (only for hi < 16)
+                    bases = reverse_fields(gwindow16(pk, lo16, ndw) << (2u * miss)) ^ 0xffffffffu;
+                    mk = reverse_fields(gmarks16(in.ref_mask, lo16) << (2u * miss));
+                }
+                if (v < 16u) { const uint32_t keep = (1u << (2u * v)) - 1u; bases &= keep; mk = (mk & keep) | (0x55555555u & ~keep); }
+                marks = mk;
+                bases &= ~(marks * 3u);                                         // no base: 0, marked
+            } else if (!pk && ww * 16u < len) {
                 const uint32_t x0 = ww * 16u;
                 u32x4u1 raw = {0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu};     // 'N'
                 // base x0 + x is byte x0 + x of the slice, or, read backwards, byte len - 1 - x0 - x
@@ -2692,14 +2771,13 @@ struct gba_ctx {
                                      // can use (1920 waves here); measured on 10-kb pairs: 245 760 pairs in one piece 658 GCUPS,
                                      // in two staggered parts 734, a single batch of 122 880 pairs 714
     // device scratch (grow-only)
-    Buf b_ref;                       // reference for batches without a target arena (gba_set_reference)
+    Buf b_ref, b_refm;               // reference for batches without a target arena (gba_set_reference): 2 bits per base, and a mask bit per base
     uint64_t ref_len = 0;
     Buf s_trc;
     Buf b_pair32[N_PAIR32], b_pair64[N_PAIR64], b_needed;
     Slot slot[NSLOT];
     // host-buffer batches: device copies of the caller's batch, the copy streams, the worker thread
     Buf s_q, s_t, s_blk, s_qoff, s_toff, s_boff, s_qlen, s_tlen, s_nblk, s_res, s_cigoff, s_gout;
-    Buf s_qpk;                       // host-buffer batches with packed reads: the packed bytes as they arrive
     Buf s_prof;                      // host-buffer batches with a quality-value profile: its device copy
     Buf kb[9];                       // gba_kband: band widths, strand flags, cost profile, arrow offsets, matrix, arrows, block slots, counts, offsets
     hipStream_t s_in = nullptr, s_out = nullptr;     // host-to-device and device-to-host copies, beside the kernels
@@ -3028,13 +3106,10 @@ int stage_part(gba_ctx *c, HostIO &io, uint32_t first, uint32_t cnt, hipEvent_t 
             if (hi > have[1]) { pieces[np][0] = have[1]; pieces[np][1] = hi; np++; have[1] = hi; }
         }
         for (int k = 0; k < np; k++) {
-            if (packed) {
+            if (packed) {           // the packed bytes go where the kernels read them: nothing is spelt out
                 const uint64_t f16 = pieces[k][0] / 16, n16 = (pieces[k][1] - pieces[k][0]) / 16;
-                int rc = move((char *)c->s_qpk.ptr + f16 * 4, a.src + f16 * 4, (size_t)n16 * 4);
+                int rc = move((char *)a.buf->ptr + f16 * 4, a.src + f16 * 4, (size_t)n16 * 4);
                 if (rc) return rc;
-                hipLaunchKernelGGL(k_unpack2, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const uint32_t *)c->s_qpk.ptr,
-                                   (u32x4 *)a.buf->ptr, f16, n16);
-                HIPCHK(c, hipGetLastError());
                 continue;
             }
             int rc = move((char *)a.buf->ptr + pieces[k][0] * a.esz, a.src + pieces[k][0] * a.esz,
@@ -3128,10 +3203,11 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
     g.q_arena = b->q_arena; g.t_arena = b->t_arena; g.blocks = b->blocks;
     g.t_rc = b->t_rc;
     g.q_arena_bytes = b->q_arena_bytes; g.t_arena_bytes = b->t_arena_bytes; g.n_blocks_total = b->n_blocks_total;
-    if (!g.t_arena) {            // targets are windows of the ctx reference
+    if (!g.t_arena) {            // targets are windows of the ctx reference (kept packed)
         if (!c->b_ref.ptr) return GBA_E_STATE;
-        g.t_arena = (const uint8_t *)c->b_ref.ptr; g.t_arena_bytes = c->ref_len;
+        g.ref_pk = (const uint32_t *)c->b_ref.ptr; g.ref_mask = (const uint32_t *)c->b_refm.ptr; g.t_arena_bytes = c->ref_len;
     }
+    if (b->q_packed) g.q_pk = (const uint32_t *)b->q_arena;       // the reads stay 2 bits per base in device memory
     g.q_off = b->q_off; g.t_off = b->t_off; g.blk_off = b->blk_off;
     g.q_len = b->q_len; g.t_len = b->t_len; g.n_blk = b->n_blk;
     g.guide_status = c->cur_guide_status;
@@ -3281,7 +3357,9 @@ int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides
     SdpIn in;
     in.q_arena = b->q_arena; in.t_arena = b->t_arena; in.t_rc = b->t_rc;
     in.q_arena_bytes = b->q_arena_bytes; in.t_arena_bytes = b->t_arena_bytes;
-    if (!in.t_arena) { in.t_arena = (const uint8_t *)c->b_ref.ptr; in.t_arena_bytes = c->ref_len; }
+    in.q_pk = b->q_packed ? (const uint32_t *)b->q_arena : nullptr;
+    in.ref_pk = in.ref_mask = nullptr;
+    if (!in.t_arena) { in.ref_pk = (const uint32_t *)c->b_ref.ptr; in.ref_mask = (const uint32_t *)c->b_refm.ptr; in.t_arena_bytes = c->ref_len; }
     in.q_off = b->q_off; in.t_off = b->t_off; in.q_len = b->q_len; in.t_len = b->t_len;
     // the one thing the host must know of the batch: its longest read and window (they size the kernel's LDS)
     hipLaunchKernelGGL(k_sdp_max, dim3((n + 255) / 256), dim3(256), 0, s, in, n, k.k, (uint32_t *)(needed + 1));
@@ -3488,12 +3566,11 @@ void gba_destroy(gba_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &b : c->b_pair32) release(b);
     for (auto &b : c->b_pair64) release(b);
-    Buf *bs[] = {&c->b_ref, &c->s_trc, &c->b_needed,
+    Buf *bs[] = {&c->b_ref, &c->b_refm, &c->s_trc, &c->b_needed,
                  &c->s_q, &c->s_t, &c->s_blk, &c->s_qoff, &c->s_toff, &c->s_boff, &c->s_qlen, &c->s_tlen,
                  &c->s_nblk, &c->s_res, &c->s_cigoff, &c->s_gout};
     for (Buf *b : bs) release(*b);
     for (auto &b : c->kb) release(b);
-    release(c->s_qpk);
     release(c->s_prof);
     if (c->h_needed) (void)hipHostFree(c->h_needed);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -3595,7 +3672,7 @@ int gba_set_scoring(gba_ctx *c, const gba_scoring *s)
 
 int gba_submit_device(gba_ctx *c, const gba_batch *b, gba_results *out)
 {
-    if (!c || !b || !out || b->q_packed) return GBA_E_INVALID;
+    if (!c || !b || !out || (b->q_packed && ((uintptr_t)b->q_arena & 3u))) return GBA_E_INVALID;
     if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
     if (b->n_pairs && (!out->pairs || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
     if (out->cigar_ops && !out->cigar_off) return GBA_E_INVALID;
@@ -3613,7 +3690,7 @@ int gba_submit_device(gba_ctx *c, const gba_batch *b, gba_results *out)
 
 int gba_submit_device_noalloc(gba_ctx *c, const gba_batch *b, gba_results *out)
 {
-    if (!c || !b || !out || b->q_packed) return GBA_E_INVALID;
+    if (!c || !b || !out || (b->q_packed && ((uintptr_t)b->q_arena & 3u))) return GBA_E_INVALID;
     if (!c->have_scoring || c->in_flight) return GBA_E_STATE;
     if (b->n_pairs && (!out->pairs || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
     if (out->cigar_ops && !out->cigar_off) return GBA_E_INVALID;
@@ -3649,12 +3726,12 @@ static int run_host_batch(gba_ctx *c, const gba_batch *b, gba_results *out)
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     struct { Buf *buf; size_t bytes; } need[] = {
-        {&c->s_q, (size_t)b->q_arena_bytes}, {&c->s_t, b->t_arena ? (size_t)b->t_arena_bytes : 0},
+        {&c->s_q, b->q_packed ? (size_t)b->q_arena_bytes / 4 + 32 : (size_t)b->q_arena_bytes}, {&c->s_t, b->t_arena ? (size_t)b->t_arena_bytes : 0},
         {&c->s_blk, (size_t)b->n_blocks_total * sizeof(gba_block)},
         {&c->s_qoff, (size_t)n * 8}, {&c->s_toff, (size_t)n * 8}, {&c->s_boff, (size_t)n * 8},
         {&c->s_qlen, (size_t)n * 4}, {&c->s_tlen, (size_t)n * 4}, {&c->s_nblk, (size_t)n * 4},
         {&c->s_trc, b->t_rc ? (size_t)n : 0}, {&c->s_res, (size_t)n * sizeof(gba_pair_result)},
-        {&c->s_cigoff, cig ? ((size_t)n + 1) * 8 : 0}, {&c->s_qpk, b->q_packed ? (size_t)b->q_arena_bytes / 4 + 16 : 0},
+        {&c->s_cigoff, cig ? ((size_t)n + 1) * 8 : 0},
         {&c->s_prof, b->q_profile ? (size_t)b->q_arena_bytes * 22 : 0}};
     for (auto &x : need) if ((rc = ensure(c, *x.buf, x.bytes + 16))) return rc;
     gba_batch db = *b;
@@ -3808,7 +3885,7 @@ int gba_set_guide_producer(gba_ctx *c, const gba_sdp_params *sp)
 
 int gba_sdp_device(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides *out)
 {
-    if (!c || !b || !sp || !out || b->q_packed) return GBA_E_INVALID;
+    if (!c || !b || !sp || !out || (b->q_packed && ((uintptr_t)b->q_arena & 3u))) return GBA_E_INVALID;
     if (c->in_flight) return GBA_E_STATE;
     if (b->n_pairs && (!b->q_arena || !b->q_off || !b->t_off || !b->q_len || !b->t_len)) return GBA_E_INVALID;
     if (b->n_pairs && (!out->status || !out->chain_score || !out->n_blk || !out->blk_off || (!out->blocks && out->blocks_capacity))) return GBA_E_INVALID;
@@ -3819,7 +3896,7 @@ int gba_sdp_device(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba
 // The same from and to host buffers: the sequences travel in, the guides travel out (synchronous).
 int gba_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides *out)
 {
-    if (!c || !b || !sp || !out || b->q_packed) return GBA_E_INVALID;
+    if (!c || !b || !sp || !out) return GBA_E_INVALID;
     if (c->in_flight) return GBA_E_STATE;
     const uint32_t n = b->n_pairs;
     out->blocks_needed = 0;
@@ -3830,7 +3907,8 @@ int gba_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     struct { Buf *buf; const void *src; size_t bytes; } in[] = {
-        {&c->s_q, b->q_arena, (size_t)b->q_arena_bytes}, {&c->s_t, b->t_arena, b->t_arena ? (size_t)b->t_arena_bytes : 0},
+        {&c->s_q, b->q_arena, b->q_packed ? ((size_t)b->q_arena_bytes + 15) / 16 * 4 : (size_t)b->q_arena_bytes},
+        {&c->s_t, b->t_arena, b->t_arena ? (size_t)b->t_arena_bytes : 0},
         {&c->s_qoff, b->q_off, (size_t)n * 8}, {&c->s_toff, b->t_off, (size_t)n * 8},
         {&c->s_qlen, b->q_len, (size_t)n * 4}, {&c->s_tlen, b->t_len, (size_t)n * 4}, {&c->s_trc, b->t_rc, b->t_rc ? (size_t)n : 0}};
     hipStream_t s = c->slot[0].s;
@@ -3872,10 +3950,30 @@ int gba_set_reference(gba_ctx *c, const uint8_t *ref, uint64_t len)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->ref_len = 0;
-    if (len == 0) { release(c->b_ref); return GBA_OK; }
-    int rc = ensure(c, c->b_ref, (size_t)len + 16);
+    if (len == 0) { release(c->b_ref); release(c->b_refm); return GBA_OK; }
+    // kept packed: 2 bits per base (len / 4 bytes) and a mask bit per base (len / 8 bytes); the letters pass through a
+    // staging buffer a chunk at a time
+    const uint64_t groups = (len + 31) / 32;
+    int rc = ensure(c, c->b_ref, (size_t)(groups * 8 + 16));
+    if (rc == GBA_OK) rc = ensure(c, c->b_refm, (size_t)(groups * 4 + 16));
     if (rc) return rc;
-    HIPCHK(c, hipMemcpy(c->b_ref.ptr, ref, (size_t)len, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemsetAsync((char *)c->b_ref.ptr + groups * 8, 0, 16, c->stream));
+    HIPCHK(c, hipMemsetAsync((char *)c->b_refm.ptr + groups * 4, 0, 16, c->stream));
+    const uint64_t chunk = 64ull << 20;               // letters per chunk, a multiple of 32
+    void *stage = nullptr;
+    HIPCHK(c, hipMalloc(&stage, (size_t)(len < chunk ? len : chunk)));
+    for (uint64_t at = 0; at < len; at += chunk) {
+        const uint64_t n = len - at < chunk ? len - at : chunk;
+        hipError_t e = hipMemcpyAsync(stage, ref + at, (size_t)n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_ref_pack, dim3((unsigned)((n + 32 * 256 - 1) / (32 * 256))), dim3(256), 0, c->stream, (const uint8_t *)stage, n, at,
+                               (uint32_t *)c->b_ref.ptr, (uint32_t *)c->b_refm.ptr);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);       // the staging buffer is reused; the caller's letters may go away
+        if (e != hipSuccess) { (void)hipFree(stage); c->last_hip = (int)e; return GBA_E_HIP; }
+    }
+    HIPCHK(c, hipFree(stage));
     c->ref_len = len;
     return GBA_OK;
 }

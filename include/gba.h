@@ -149,11 +149,13 @@ typedef struct {
     const gba_block *blocks; const uint64_t *blk_off; const uint32_t *n_blk;
     uint64_t q_arena_bytes, t_arena_bytes, n_blocks_total;   /* extents of the three arenas */
     const uint8_t *t_rc;        /* per pair, nonzero: target = reverse complement of its slice; NULL: none */
-    uint32_t q_packed;          /* gba_submit only.  Nonzero: q_arena holds the reads 2 bits per base instead of letters: base x of
-                                   the arena is bits 2 (x & 3) .. 2 (x & 3) + 1 of byte x >> 2, A, C, G, T = 0 .. 3 (a read with
-                                   other letters cannot be packed: send that batch as letters).  q_off, q_len and q_arena_bytes
-                                   still count BASES; the packed arena holds ((q_arena_bytes + 15) / 16) * 4 bytes.  A quarter
-                                   of the bytes cross the link; the device spells the letters out again as each part arrives. */
+    uint32_t q_packed;          /* Nonzero: q_arena holds the reads 2 bits per base instead of letters: base x of the arena is
+                                   bits 2 (x & 3) .. 2 (x & 3) + 1 of byte x >> 2, A, C, G, T = 0 .. 3 (a read with other
+                                   letters cannot be packed: send that batch as letters).  q_off, q_len and q_arena_bytes
+                                   still count BASES; the packed arena holds ((q_arena_bytes + 15) / 16) * 4 bytes and starts
+                                   on a 4-byte boundary.  A quarter of the bytes cross the link and stay that way in device
+                                   memory: the kernels read the packed form.  Every entry point that takes a gba_batch
+                                   accepts it, host or device buffers, with or without blocks. */
     const int16_t *q_profile;   /* NULL, or the costs of a quality-value scorer in place of matrix, ins and del for the DP of this
                                    batch: GuidedAlign(qSeq, tSeq, alignmentCandidate, idsScoreFn, band, ...) of
                                    iblasr/BlasrUtilsImpl.hpp:705-717, and with GBA_MODE_AFFINE the AffineGuidedAlign call of :707-710.
@@ -334,9 +336,11 @@ int gba_sdp(gba_ctx *ctx, const gba_batch *host_batch, const gba_sdp_params *par
  * take such batches (GBA_E_INVALID). */
 int gba_set_guide_producer(gba_ctx *ctx, const gba_sdp_params *params);
 
-/* Keeps a copy of the reference (genome, ASCII; `ref` is a host pointer) in device
- * memory for batches whose t_arena is NULL; len == 0 drops it.  Replaces the
- * per-candidate window copies out of the genome, iblasr/BlasrAlignImpl.hpp:727-743. */
+/* Keeps the reference (genome, ASCII; `ref` is a host pointer) in device memory for batches whose
+ * t_arena is NULL; len == 0 drops it.  It is kept 2 bits per base plus one mask bit per base for the
+ * letters outside ACGT (N runs): 3 / 8 of a byte per base, 24 MB for a 64 Mb chromosome; windows are cut
+ * out of the packed form (reverse strand: read backwards and complemented) where the kernels need them.
+ * Replaces the per-candidate window copies out of the genome, iblasr/BlasrAlignImpl.hpp:727-743. */
 int gba_set_reference(gba_ctx *ctx, const uint8_t *ref, uint64_t len);
 
 /* ---- fixed-band aligners: the other pairwise aligners of the refine stage --------------------
