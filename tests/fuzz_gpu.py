@@ -9,7 +9,10 @@ sample of pairs with blasr_amd.emit.cigar_ops on the returned blocks; every thir
 guide producer (gba_sdp, random tuple size / penalties / fragment budget) on the round's sequences
 against oracle/sdp_oracle.c; every third round runs the fixed-band aligners (gba_kband: random type, gap model, costs,
 bands, strand flags, cost profile) on a sample of the round's sequences against oracle/kband_oracle.c; every fourth round
-repeats the batch with the costs of a quality-value scorer (gba_batch.q_profile) against gbo_align_qv.
+repeats the batch with the costs of a quality-value scorer (gba_batch.q_profile) against gbo_align_qv; every fifth round
+(linear gaps) repeats it under the Local end rule (gba_scoring.align_type) against the oracle's; every fifth round repeats it
+with the reads 2 bits per base and the targets as windows of a resident (packed) reference, on both strands, against the
+same calls on letters and explicit targets.
 Mismatches are written to gpurun_out/fuzz_fail_<k>.json with everything needed to replay them.
 
 usage: python tests/fuzz_gpu.py [--seconds 120] [--seed 1]
@@ -239,6 +242,71 @@ def check_qv(rng, api, oracle, _lib, ctx, pool, batch, kw):
     return None
 
 
+def compare_with_oracle(_lib, oracle, pool, batch, P, pairs, blocks, tag=""):
+    """Every pair result and block of a host run against the oracle's; None or the first difference."""
+    n = int(batch["n_pairs"])
+    chunk = max(1, n // 16)
+    futs = [pool.submit(oracle.align_batch, batch, P, f, min(chunk, n - f)) for f in range(0, n, chunk)]
+    ores, oblk = [], []
+    for f in futs:
+        r, b = f.result()
+        ores += list(r); oblk += b
+    for p in range(n):
+        o, k = ores[p], pairs[p]
+        ko = int(k["status"])
+        if ko in (_lib.PAIR_TOO_WIDE, _lib.PAIR_TOO_LONG):
+            continue
+        if int(o["status"]) != ko:
+            return (p, tag + "status", int(o["status"]), ko)
+        if ko != 0:
+            continue
+        for fld in FIELDS:
+            if int(o[fld]) != int(k[fld]):
+                return (p, tag + fld, int(o[fld]), int(k[fld]))
+        kb = blocks[int(k["blk_off"]):int(k["blk_off"]) + int(k["n_blk"])]
+        ob = oblk[p]
+        if len(kb) != len(ob) or not (np.array_equal(kb["q_pos"], ob["q_pos"]) and np.array_equal(kb["t_pos"], ob["t_pos"])
+                                      and np.array_equal(kb["length"], ob["length"])):
+            return (p, tag + "blocks", len(ob), len(kb))
+    return None
+
+
+def check_local(api, oracle, _lib, ctx, pool, batch, kw):
+    """The round's batch under the Local end rule (free start, end in the cheapest cell of the band) against the oracle's."""
+    ctx.set_scoring(api.make_scoring(**kw, align_type=_lib.ALIGN_LOCAL))
+    pairs, blocks, rc = ctx.refine_host(batch)
+    if rc != 0:
+        return (0, "local_rc", 0, rc)
+    return compare_with_oracle(_lib, oracle, pool, batch, oracle.make_params(**kw, align_type=oracle.ALIGN_LOCAL), pairs, blocks, "local_")
+
+
+def check_packed(rng, api, _lib, ctx, batch, want, want_blocks):
+    """The round's batch with its target arena resident as the reference (packed 2 bits per base plus a mask bit, whatever
+    letters it holds) and the targets given as windows of it, the reads 2 bits per base when they have no other letters:
+    the same bytes as from letters and explicit targets; then the same comparison with random strand flags."""
+    n = int(batch["n_pairs"])
+    try:
+        packed = api.pack_reads_2bit(batch)
+    except ValueError:
+        packed = batch
+    ctx.set_reference(batch["t_arena"])
+    try:
+        win = {k: v for k, v in packed.items() if k != "t_arena"}
+        got, got_blocks, rc = ctx.refine_host(win)
+        if rc != 0 or got.tobytes() != want.tobytes() or got_blocks.tobytes() != want_blocks.tobytes():
+            diff = [p for p in range(n) if got[p].tobytes() != want[p].tobytes()]
+            return (diff[0] if diff else 0, "packed windows", rc, len(diff))
+        flags = rng.integers(0, 2, n).astype(np.uint8)
+        a, ab, rca = ctx.refine_host(dict(batch, t_rc=flags))
+        b, bb, rcb = ctx.refine_host(dict(win, t_rc=flags))
+        if rca != rcb or a.tobytes() != b.tobytes() or ab.tobytes() != bb.tobytes():
+            diff = [p for p in range(n) if a[p].tobytes() != b[p].tobytes()]
+            return (diff[0] if diff else 0, "packed windows, both strands", rcb, len(diff))
+    finally:
+        ctx.set_reference(None)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
@@ -256,7 +324,7 @@ def main():
     ctxs = (api.Context(0), ctx_quad)
     pool = ThreadPoolExecutor(16)
     t_end = time.time() + args.seconds
-    rounds = pairs_done = fails = unsupported = cigar_rounds = sdp_rounds = kband_rounds = qv_rounds = 0
+    rounds = pairs_done = fails = unsupported = cigar_rounds = sdp_rounds = kband_rounds = qv_rounds = packed_rounds = local_rounds = 0
     hist = {}
     modes = {}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -336,6 +404,12 @@ def main():
             kband_rounds += 1
             if bad:
                 kw = dict(kw, kband=kkw)
+        if not bad and rounds % 5 == 0 and cig is None:
+            bad = check_packed(rng, api, _lib, ctx, batch, pairs, blocks)
+            packed_rounds += 1
+        if not bad and rounds % 5 == 1 and kw["mode"] == _lib.MODE_LINEAR:
+            bad = check_local(api, oracle, _lib, ctx, pool, batch, kw)
+            local_rounds += 1
         rounds += 1; pairs_done += n
         for v, c in zip(*np.unique(pairs["status"], return_counts=True)):
             hist[int(v)] = hist.get(int(v), 0) + int(c)
@@ -358,7 +432,8 @@ def main():
         if rounds % 20 == 0:
             print("rounds %d pairs %d fails %d unsupported-scoring %d" % (rounds, pairs_done, fails, unsupported), flush=True)
     print("DONE rounds %d pairs %d fails %d unsupported-scoring %d" % (rounds, pairs_done, fails, unsupported), flush=True)
-    print("status histogram", hist, "pairs per mode", modes, "rounds with CIGAR check", cigar_rounds, "rounds with guide production", sdp_rounds, "rounds with fixed-band aligners", kband_rounds, "rounds with quality-value costs", qv_rounds, flush=True)
+    print("status histogram", hist, "pairs per mode", modes, "rounds with CIGAR check", cigar_rounds, "rounds with guide production", sdp_rounds, "rounds with fixed-band aligners", kband_rounds, "rounds with quality-value costs", qv_rounds,
+          "rounds with packed reads and reference windows", packed_rounds, "rounds under the Local end rule", local_rounds, flush=True)
     sys.exit(1 if fails else 0)
 
 
