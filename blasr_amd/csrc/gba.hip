@@ -65,6 +65,10 @@ constexpr int LANE_CLS_AFFINE = 2;           // affine gaps: 32 and 64 slots; wi
 constexpr int PAD_SLOTS = 3;                 // spare slots behind a ring
 constexpr int SPAN_MARGIN = 4;               // a pair fits a class if its widest shift + width <= slots - SPAN_MARGIN (k_fill touches up to 7 slots past a row end)
 constexpr int CAP_LINEAR = 32, CAP_AFFINE = 40;   // cells per lane per step of k_fill (band 10 rows are 21+ cells, band 16 rows 33+)
+// k_fill takes one word of a pair's guide stream per step, so a row of more cells than one step computes is followed in the
+// stream by a continuation word (zero, never looked at) for every further step it needs.
+__host__ __device__ constexpr uint32_t cont_words(uint32_t W, uint32_t cap) { return W > cap ? (W - 1u) / cap : 0u; }
+__host__ __device__ constexpr uint32_t step_cap(int mode) { return mode == GBA_MODE_AFFINE ? (uint32_t)CAP_AFFINE : (uint32_t)CAP_LINEAR; }
 constexpr size_t ARENA_SLACK = 16384 + 256;          // bytes in front of the record / target-code arenas: k_traceback's windows start before a pair's data
 // slots of lane class c: 32, 64, and a widest class of `top` slots (128 for linear gaps, 96 for affine)
 __host__ __device__ constexpr uint32_t cls_slots(int c, uint32_t top) { return c < 2 ? 32u << c : top; }
@@ -169,13 +173,16 @@ __device__ __forceinline__ uint64_t tc_offset(const Dev &d, uint32_t p) { return
 // 128 (the bias of the substitution table) + score_a, and up to T moves along a row, each adding at
 // most score_b; the sum must stay below score_lim (the value from which words count as unreachable),
 // otherwise the pair is TOO_LONG.
-__global__ void k_meta(Dev d, int mode, int kband_k, uint32_t score_a, uint32_t score_b, uint32_t score_lim)
+__global__ void k_meta(Dev d, int mode, int kband_k, uint32_t score_a, uint32_t score_b, uint32_t score_lim, int band, int max_band)
 {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= d.n) return;
     int st = GBA_PAIR_OK;
     uint32_t qS = 0, tS = 0, Q = 0, T = 0;
-    uint64_t drift_sum = 0;
+    uint64_t drift_sum = 0, cont_sum = 0;
+    // continuation words: a row's width is at most w + wp + 1 with its two half-widths of k_guide (hi = c + w, lo >= c - wp)
+    const uint32_t cap = step_cap(mode);
+    const uint32_t gB = (uint32_t)min(band, max_band), gfirst = max((uint32_t)max_band, gB);
     const uint32_t ql = d.q_len[p], tl = d.t_len[p];
     uint32_t nb = 0;
     // slices that leave their arena (a window outside the reference, a corrupt offset) are never touched
@@ -199,12 +206,22 @@ __global__ void k_meta(Dev d, int mode, int kband_k, uint32_t score_a, uint32_t 
             for (uint32_t i = 0; i < nb; i++) {
                 const uint32_t bq = bl[i].q_pos, bt = bl[i].t_pos, len = bl[i].length;
                 if (len == 0 || (uint64_t)bq + len > ql || (uint64_t)bt + len > tl) st = GBA_PAIR_BAD_GUIDE;
+                uint64_t adr = 0, wprev = gB;
                 if (i == 0) { qS = bq; tS = bt; }
                 else if (bq < qe || bt < te) st = GBA_PAIR_BAD_GUIDE;
                 else {
                     const int64_t dr = (int64_t)(bt - te) - (int64_t)(bq - qe);
-                    drift_sum += (uint64_t)(dr < 0 ? -dr : dr);
+                    adr = (uint64_t)(dr < 0 ? -dr : dr);
+                    drift_sum += adr;
+                    const uint64_t wg = min((uint64_t)max_band, (uint64_t)band + adr);       // the gap's rows
+                    const uint64_t qGap = (uint64_t)bq - qe;
+                    cont_sum += qGap * cont_words((uint32_t)min(2 * wg + 1, (uint64_t)MAX_COLS + 1), cap);
+                    if (qGap) wprev = wg;
                 }
+                // the block's first row reaches back to where the row before it began (the centre moves on by at most
+                // 1 + |drift|), and never further than its own lower half-width; its other rows are 2 B + 1 wide at most
+                cont_sum += cont_words((uint32_t)min(min((uint64_t)gB + gfirst + 1, gB + wprev + 2 + adr), (uint64_t)MAX_COLS + 1), cap);
+                cont_sum += (uint64_t)(len - 1u) * cont_words(2u * gB + 1u, cap);
                 qe = (uint64_t)bq + len; te = (uint64_t)bt + len;
             }
             if (st == GBA_PAIR_OK) { Q = (uint32_t)qe - qS; T = (uint32_t)te - tS; }
@@ -220,7 +237,9 @@ __global__ void k_meta(Dev d, int mode, int kband_k, uint32_t score_a, uint32_t 
     // most one partly filled EXT word per row that needs any (the boundary row, the first row of
     // a gap, the first row of a block).  Rounded up to whole 64-byte sectors plus one sector that
     // k_fill may prefetch past the end.
-    uint64_t wc = (uint64_t)Q + 1 + ((uint64_t)T + 1 + drift_sum) / 8 + 2ull * nb + 4;
+    if (mode == GBA_MODE_KBAND) cont_sum = ((uint64_t)Q + 1) * cont_words((uint32_t)min(2ull * (uint64_t)kband_k + 1, (uint64_t)MAX_COLS + 1), cap);
+    else cont_sum += cont_words(gB + 1u, cap);          // the boundary row
+    uint64_t wc = (uint64_t)Q + 1 + ((uint64_t)T + 1 + drift_sum) / 8 + 2ull * nb + 4 + cont_sum;
     wc = ((wc + 15) & ~15ull) + 16;
     d.wcap[p] = st == GBA_PAIR_OK ? (uint32_t)wc : 0;
     d.span[p] = 0; d.ncells[p] = 0; d.lo_last[p] = 0; d.dp_score[p] = 0; d.cls[p] = NCLS; d.recdw[p] = 0;
@@ -499,7 +518,8 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
         const uint32_t W = e - lo, dl = lo - lo_prev;
         // columns entering on the right: [hi_prev + 1, hi]
         const uint32_t nnew = valid && e > e_prev ? e - e_prev : 0u, cnew = e_prev;
-        const uint32_t words = valid ? 1u + (nnew > 3u ? (nnew + 4u) >> 3 : 0u) : 0u;
+        const uint32_t ncont = valid ? cont_words(W, step_cap(mode)) : 0u;
+        const uint32_t words = valid ? 1u + (nnew > 3u ? (nnew + 4u) >> 3 : 0u) + ncont : 0u;
         const uint32_t incl = wave_scan_sum(words);
         const uint32_t off = nw + incl - words;
         nw += (uint32_t)__builtin_amdgcn_readlane((int32_t)incl, 63);
@@ -526,6 +546,8 @@ __global__ __launch_bounds__(64) void k_guide(Dev d, int mode, int band, int max
                 if (left < 8u) ew &= (1u << (3u * left)) - 1u;
                 if (o < wcap) g[o] = ew;
             }
+            for (uint32_t x = 0; x < ncont; x++, o++)
+                if (o < wcap) g[o] = 0;
             if (r == Q) d.lo_last[p] = lo;
         }
     }
@@ -661,9 +683,9 @@ __global__ __launch_bounds__(SCAN_T) void k_plan(Dev d, int ncls, int has_wide, 
 // ---------------------------------------------------------------- k_fill
 // One LANE per pair, 64 pairs per wave.  Lanes are NOT in row lock step: every lane walks its own
 // guide stream.  One step of the (wave-uniform) loop lets each lane
-//   1. if its current row is finished, pop the next ROW word: new width / shift / query base,
+//   1. if its current row is finished, take the step's word as the next ROW word: new width / shift / query base,
 //      write the INFW words of three entering columns; or, if the row still has entering columns
-//      pending, pop an EXT word and write eight more;
+//      pending, take it as an EXT word and write eight more; (otherwise it is a continuation word)
 //   2. compute up to CAP cells of its current row (rows wider than CAP continue next step).
 // A lane with a 21-cell row and a lane with a 60-cell row therefore cost 2 and 4 steps, instead of
 // both paying for the widest row of the wave.
@@ -677,23 +699,19 @@ __global__ __launch_bounds__(SCAN_T) void k_plan(Dev d, int ncls, int has_wide, 
 // of 3 / 8 entering columns), which is why a pair's widest shift + width must stay SPAN_MARGIN
 // below the ring size.
 //
-// Guide words are read a 64-byte sector (16 words) at a time into registers R0..R3; group A holds
-// the unread words of the current 4-word group (A.x is the next one; a pop shifts the group down)
-// and is refilled from R0..R3 in turn.  When A takes the last group of the sector, the lane
-// requests the next sector into R0..R3: four 16-byte loads from one inline-asm block that narrows
-// EXEC to the requesting lanes itself (inside a C++ branch the compiler gives a load a scratch
-// destination and copies it at the end of the branch, before the data has arrived).  The block
-// begins with s_waitcnt vmcnt(0): what the previous step requested has arrived (it had a whole
-// step for that) three pops before R0 can be needed, whatever the hardware does with loads whose
-// EXEC is empty and in whatever order memory operations complete; it is the only vector-memory
-// wait in the loop.  (Waiting only for operations older than the last two steps, with requests
-// half a sector earlier, was tried: not faster.)  Nothing between two executions of the block may
-// move R0..R3 to other registers (check the ISA after changing the loop).  A sector is fetched
-// from memory once and used up by its lane; with one
-// 16-byte load per four pops the L2 had to keep a 128-byte line per lane for 32 pops, which it
-// cannot do for 130 k lanes (measured: at two waves per SIMD everywhere the guide loads alone
-// made the launch 45 % longer).  Record dwords are stored directly.  No LDS is spent on the
-// stream: LDS is what limits the waves per CU.
+// Guide words: a lane takes exactly ONE word of its pair's stream per step -- the ROW word of a new row, an EXT word of
+// entering columns, or, while a row wider than CAP is still being computed, a continuation word that k_guide put there
+// for the purpose (zero, never looked at).  Lanes are out of step in ROWS, but in step in stream WORDS: word number `it`
+// of every lane's stream belongs to step `it`, so which register holds this step's word is the same for the whole wave
+// and is fixed by the loop counter, not selected per lane.  The loop takes four steps per turn on one 16-byte group of
+// the 64-byte sector held in R0..R3; the sector after it waits in S0..S3, requested by the whole wave at once a full
+// sector (sixteen steps) before its first word is needed, with ordinary loads whose arrival the compiler tracks.  A
+// sector is fetched from memory once and used up by its lane (with one 16-byte load per four words the L2 had to keep a
+// 128-byte line per lane for 32 steps, which it cannot do for 130 k lanes; measured at two waves per SIMD everywhere: the
+// guide loads alone made the launch 45 % longer).  (Before, a lane took a word only when it had a use for one: the unread
+// words shifted through a group of four registers refilled from R0..R3 by per-lane selects, and a lane asked for its next
+// sector when it had used one up, from an inline-asm block that narrowed EXEC: about 60 of 575 instructions per step.)
+// Record dwords are stored directly.  No LDS is spent on the stream: LDS is what limits the waves per CU.
 constexpr int LDS_TAB = 16;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -735,13 +753,14 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     char *recb = (char *)(d.rec + rbase);
     uint32_t rob = (uint32_t)(d.rec_off[p] - rbase) * 4u;
 
-    // stream words: see above.  Streams start 64-byte aligned and are whole sectors long.
+    // stream words: R0..R3 hold the sector in use, S0..S3 the one after it, requested a whole sector (sixteen steps) before
+    // its first word is looked at.  Streams start 64-byte aligned and are whole sectors long; a lane that has come to the
+    // end of its stream (it has finished by then) reads its last sector again.
     u32x4 R0 = *(const u32x4 *)(st), R1 = *(const u32x4 *)(st + 4), R2 = *(const u32x4 *)(st + 8), R3 = *(const u32x4 *)(st + 12);
-    u32x4 A = R0;
-    uint32_t na = 4, gi = 1, ws = 16;        // words left in A; group of the sector that refills A next; first word of the next sector
-    // No pair needs more steps than stream words plus one step per CAP cells; the loop stops there
-    // whatever the stream holds.
-    uint32_t max_steps = wcap + (uint32_t)(d.ncells[p] / (uint32_t)CAP) + 16u;
+    uint32_t ws = min(16u, wcap - 16u);      // first word of the sector in S
+    u32x4 S0 = *(const u32x4 *)(st + ws), S1 = *(const u32x4 *)(st + ws + 4), S2 = *(const u32x4 *)(st + ws + 8), S3 = *(const u32x4 *)(st + ws + 12);
+    // No pair needs more steps than its stream has words; the loop stops there whatever the stream holds.
+    uint32_t max_steps = wcap;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) max_steps = max(max_steps, (uint32_t)__shfl_xor((int)max_steps, o, 64));
 
@@ -752,175 +771,165 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     bool first = true, finished = !live;
     uint32_t final_word = INFW;
     // the matrix row of the next word's query base is fetched one step ahead
-    uint32_t nmlo = tab[((A.x >> 10) & 7u) * 2], nmhi = tab[((A.x >> 10) & 7u) * 2 + 1];
+    uint32_t nmlo = tab[((R0.x >> 10) & 7u) * 2], nmhi = tab[((R0.x >> 10) & 7u) * 2 + 1];
 
-    for (uint32_t it = 0; it < max_steps && __any(!finished); it++) {
-        // ---- 1. word pop
-        const bool pop_ext = !finished && ext_left > 0u;
-        const bool pop_row = !finished && ext_left == 0u && k0 >= W && rows_left > 0u;
-        const uint32_t word = A.x;
-        if (pop_row) {
-            rows_left--;
-            Wp = W;
-            W = word & ROW_W_MASK; dsh = (word >> 13) & 1023u;
-            mlo = nmlo; mhi = nmhi;
-            const uint32_t tot = dsh + W;
-            const uint32_t nnew = tot > Wp ? tot - Wp : 0u;
-            uint32_t *ns = lds + Wp * 64 + lane;
-            ns[0] = INFW | ((word >> 23) & 7u); ns[64] = INFW | ((word >> 26) & 7u); ns[128] = INFW | (word >> 29);
-            if constexpr (AFF) { ns[IOFF] = INFW; ns[IOFF + 64] = INFW; ns[IOFF + 128] = INFW; }
-            ext_left = nnew > 3u ? (nnew + 4u) >> 3 : 0u;
-            newslot = Wp + 3u;
-            k0 = 0;
-            left = INFW; leftD = INFW;
-            meta = word & ROW_META_MASK;
-        }
-        if (pop_ext) {
-            ext_left--;
-            uint32_t *ns = lds + newslot * 64 + lane;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                ns[j * 64] = INFW | ((word >> (3 * j)) & 7u);
-                if constexpr (AFF) ns[IOFF + j * 64] = INFW;
-            }
-            newslot += 8u;
-        }
-        uint32_t req = 0;
-        if (pop_row || pop_ext) {
-            A.x = A.y; A.y = A.z; A.z = A.w;
-            if (--na == 0u) {
-                A = gi == 0u ? R0 : gi == 1u ? R1 : gi == 2u ? R2 : R3;
-                na = 4;
-                gi = (gi + 1u) & 3u;
-                req = gi == 0u && ws + 16u <= wcap ? 1u : 0u;     // R3 has just been taken: the sector is used up
-            }
-        }
-        {
-            const uint32_t *src = st + ws;
-            uint64_t saved;
-            asm volatile("s_waitcnt vmcnt(0)\n\t"
-                         "s_mov_b64 %[sv], exec\n\t"
-                         "v_cmp_ne_u32_e32 vcc, 0, %[rq]\n\t"
-                         "s_and_b64 exec, exec, vcc\n\t"
-                         "global_load_dwordx4 %[r0], %[sp], off\n\t"
-                         "global_load_dwordx4 %[r1], %[sp], off offset:16\n\t"
-                         "global_load_dwordx4 %[r2], %[sp], off offset:32\n\t"
-                         "global_load_dwordx4 %[r3], %[sp], off offset:48\n\t"
-                         "s_mov_b64 exec, %[sv]"
-                         : [r0] "+v"(R0), [r1] "+v"(R1), [r2] "+v"(R2), [r3] "+v"(R3), [sv] "=&s"(saved)
-                         : [rq] "v"(req), [sp] "v"(src) : "vcc", "scc", "memory");
-            ws += req * 16u;
-        }
-        // ---- 2. up to CAP cells of the current row, in groups of 8
-        const bool did = !finished && ext_left == 0u && k0 < W;
-        const uint32_t rem = W - k0;
-        uint32_t ar[NAR];
-#pragma unroll
-        for (int x = 0; x < NAR; x++) ar[x] = 0;
-        // One LDS round trip for everything the step's first cells need: the diagonal predecessor of
-        // a new row's first cell and the vertical predecessors of the first 8 cells (lanes without
-        // cells this step read slots 0..7, which always exist).
-        const uint32_t *rd = lds + (did ? dsh + k0 : 0u) * 64 + lane;
-        uint32_t up[2][8], ui[2][8];
-        {
-            const uint32_t dv = lds[(max(dsh, 1u) - 1u) * 64 + lane];
-#pragma unroll
-            for (int x = 0; x < 8; x++) { up[0][x] = rd[x * 64]; if constexpr (AFF) ui[0][x] = rd[IOFF + x * 64]; }
+    // One step: `word` is this step's word of the stream, `next` the one after it.
+    auto step = [&](const uint32_t word, const uint32_t next) __attribute__((always_inline)) {
+            // ---- 1. word pop
+            const bool pop_ext = !finished && ext_left > 0u;
+            const bool pop_row = !finished && ext_left == 0u && k0 >= W && rows_left > 0u;
             if (pop_row) {
-                // INFW when the diagonal predecessor lies outside the previous row
-                diag = dsh - 1u < Wp ? dv : INFW;
-                if (first) {
-                    // row 0: linear starts from "one deletion before column 0" so that cell j costs j
-                    // deletions; affine makes the diagonal candidate of cell (0,0) cost exactly 0
-                    if constexpr (AFF) diag = (uint32_t)fc.diag0; else left = (uint32_t)(-fc.del * 32);
-                }
-                first = false;
+                rows_left--;
+                Wp = W;
+                W = word & ROW_W_MASK; dsh = (word >> 13) & 1023u;
+                mlo = nmlo; mhi = nmhi;
+                const uint32_t tot = dsh + W;
+                const uint32_t nnew = tot > Wp ? tot - Wp : 0u;
+                uint32_t *ns = lds + Wp * 64 + lane;
+                ns[0] = INFW | ((word >> 23) & 7u); ns[64] = INFW | ((word >> 26) & 7u); ns[128] = INFW | (word >> 29);
+                if constexpr (AFF) { ns[IOFF] = INFW; ns[IOFF + 64] = INFW; ns[IOFF + 128] = INFW; }
+                ext_left = nnew > 3u ? (nnew + 4u) >> 3 : 0u;
+                newslot = Wp + 3u;
+                k0 = 0;
+                left = INFW; leftD = INFW;
+                meta = word & ROW_META_MASK;
             }
-        }
-        if (did) {
-            uint32_t *wr = lds + k0 * 64 + lane;
-#pragma unroll
-            for (int G = 0; G < CAP / 8; G++) {
-                if (rem > (uint32_t)(8 * G)) {
-                    if (G + 1 < CAP / 8 && rem > (uint32_t)(8 * G + 8)) {
-#pragma unroll
+            if (pop_ext) {
+                ext_left--;
+                uint32_t *ns = lds + newslot * 64 + lane;
+    #pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    ns[j * 64] = INFW | ((word >> (3 * j)) & 7u);
+                    if constexpr (AFF) ns[IOFF + j * 64] = INFW;
+                }
+                newslot += 8u;
+            }
+            // ---- 2. up to CAP cells of the current row, in groups of 8
+            const bool did = !finished && ext_left == 0u && k0 < W;
+            const uint32_t rem = W - k0;
+            uint32_t ar[NAR];
+    #pragma unroll
+            for (int x = 0; x < NAR; x++) ar[x] = 0;
+            // One LDS round trip for everything the step's first cells need: the diagonal predecessor of
+            // a new row's first cell and the vertical predecessors of the first 8 cells (lanes without
+            // cells this step read slots 0..7, which always exist).
+            const uint32_t *rd = lds + (did ? dsh + k0 : 0u) * 64 + lane;
+            uint32_t up[2][8], ui[2][8];
+            {
+                const uint32_t dv = lds[(max(dsh, 1u) - 1u) * 64 + lane];
+    #pragma unroll
+                for (int x = 0; x < 8; x++) { up[0][x] = rd[x * 64]; if constexpr (AFF) ui[0][x] = rd[IOFF + x * 64]; }
+                if (pop_row) {
+                    // INFW when the diagonal predecessor lies outside the previous row
+                    diag = dsh - 1u < Wp ? dv : INFW;
+                    if (first) {
+                        // row 0: linear starts from "one deletion before column 0" so that cell j costs j
+                        // deletions; affine makes the diagonal candidate of cell (0,0) cost exactly 0
+                        if constexpr (AFF) diag = (uint32_t)fc.diag0; else left = (uint32_t)(-fc.del * 32);
+                    }
+                    first = false;
+                }
+            }
+            if (did) {
+                uint32_t *wr = lds + k0 * 64 + lane;
+    #pragma unroll
+                for (int G = 0; G < CAP / 8; G++) {
+                    if (rem > (uint32_t)(8 * G)) {
+                        if (G + 1 < CAP / 8 && rem > (uint32_t)(8 * G + 8)) {
+    #pragma unroll
+                            for (int x = 0; x < 8; x++) {
+                                up[(G + 1) & 1][x] = rd[(8 * G + 8 + x) * 64];
+                                if constexpr (AFF) ui[(G + 1) & 1][x] = rd[IOFF + (8 * G + 8 + x) * 64];
+                            }
+                        }
+    #pragma unroll
                         for (int x = 0; x < 8; x++) {
-                            up[(G + 1) & 1][x] = rd[(8 * G + 8 + x) * 64];
-                            if constexpr (AFF) ui[(G + 1) & 1][x] = rd[IOFF + (8 * G + 8 + x) * 64];
+                            const int k = 8 * G + x;
+                            const uint32_t u_ = up[G & 1][x];
+                            const uint32_t tcd = u_ & 7u;
+                            const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);   // selector bytes 1..3 = 0 read the zero byte
+                            const int32_t m = (int32_t)((sb << SH) + diag);
+                            const int32_t u = (int32_t)u_ + fc.cU;
+                            const int32_t l = (int32_t)left + fc.cL;
+                            if constexpr (!AFF) {
+                                const uint32_t best = (uint32_t)min(m, min(u, l));
+                                const uint32_t cw = (u_ & TAGS) | (best & ~TAGS);
+                                wr[k * 64] = cw;
+                                // arrow = bits 3..4 of best -> record bits 2k..2k+1: a field extract and a shift-or with
+                                // inline constants (left to itself the compiler shifts first and masks with a 32-bit literal,
+                                // which costs a third instruction for every second cell)
+                                uint32_t a2;
+                                asm("v_bfe_u32 %0, %1, 3, 2" : "=v"(a2) : "v"(best));
+                                if ((k & 15) == 0) ar[k >> 4] = a2;
+                                else asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(ar[k >> 4]) : "v"(a2), "s"((uint32_t)((k & 15) * 2)));
+                                left = cw;
+                            } else {
+                                // gap states: open from the match state (preferred on ties) or extend
+                                const int32_t io = (int32_t)(u_ & ~TAGS) + fc.cIO, ie = (int32_t)ui[G & 1][x] + fc.cIE;
+                                const uint32_t ig = (uint32_t)min(io, ie);                 // bit 2: 1 = extend
+                                const int32_t dop = (int32_t)left + fc.cDO, de = (int32_t)leftD + fc.cDE;
+                                const uint32_t dg = (uint32_t)min(dop, de);                // bit 1: 1 = extend
+                                const int32_t dc = (int32_t)dg + (3 << 3), ic = (int32_t)ig + (4 << 3);
+                                const uint32_t best = (uint32_t)min(min(m, min(u, l)), min(dc, ic));
+                                const uint32_t lc = best & ~TAGS;
+                                wr[k * 64] = lc | tcd;
+                                wr[IOFF + k * 64] = ig & ~TAGS;
+                                // record byte: M arrow (bits 3..5) | I bit (bit 2) | D bit (bit 1)
+                                const uint32_t rbyte = (best & 0x38u) | (ig & 4u) | (dg & 2u);
+                                ar[k >> 2] |= rbyte << ((k & 3) * 8);
+                                left = lc; leftD = dg & ~TAGS;
+                            }
+                            diag = u_;
                         }
-                    }
-#pragma unroll
-                    for (int x = 0; x < 8; x++) {
-                        const int k = 8 * G + x;
-                        const uint32_t u_ = up[G & 1][x];
-                        const uint32_t tcd = u_ & 7u;
-                        const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);   // selector bytes 1..3 = 0 read the zero byte
-                        const int32_t m = (int32_t)((sb << SH) + diag);
-                        const int32_t u = (int32_t)u_ + fc.cU;
-                        const int32_t l = (int32_t)left + fc.cL;
-                        if constexpr (!AFF) {
-                            const uint32_t best = (uint32_t)min(m, min(u, l));
-                            const uint32_t cw = (u_ & TAGS) | (best & ~TAGS);
-                            wr[k * 64] = cw;
-                            // arrow = bits 3..4 of best -> record bits 2k..2k+1
-                            const int sh = (k & 15) * 2 - 3;
-                            const uint32_t ab = sh >= 0 ? (best & 0x18u) << (sh >= 0 ? sh : 0) : (best & 0x18u) >> (sh < 0 ? -sh : 0);
-                            ar[k >> 4] |= ab;
-                            left = cw;
-                        } else {
-                            // gap states: open from the match state (preferred on ties) or extend
-                            const int32_t io = (int32_t)(u_ & ~TAGS) + fc.cIO, ie = (int32_t)ui[G & 1][x] + fc.cIE;
-                            const uint32_t ig = (uint32_t)min(io, ie);                 // bit 2: 1 = extend
-                            const int32_t dop = (int32_t)left + fc.cDO, de = (int32_t)leftD + fc.cDE;
-                            const uint32_t dg = (uint32_t)min(dop, de);                // bit 1: 1 = extend
-                            const int32_t dc = (int32_t)dg + (3 << 3), ic = (int32_t)ig + (4 << 3);
-                            const uint32_t best = (uint32_t)min(min(m, min(u, l)), min(dc, ic));
-                            const uint32_t lc = best & ~TAGS;
-                            wr[k * 64] = lc | tcd;
-                            wr[IOFF + k * 64] = ig & ~TAGS;
-                            // record byte: M arrow (bits 3..5) | I bit (bit 2) | D bit (bit 1)
-                            const uint32_t rbyte = (best & 0x38u) | (ig & 4u) | (dg & 2u);
-                            ar[k >> 2] |= rbyte << ((k & 3) * 8);
-                            left = lc; leftD = dg & ~TAGS;
-                        }
-                        diag = u_;
                     }
                 }
             }
-        }
-        nmlo = tab[((A.x >> 10) & 7u) * 2]; nmhi = tab[((A.x >> 10) & 7u) * 2 + 1];
-        if (did) {
-            // record: the arrow dwords of this step (stored whole; the tail past the row end is
-            // overwritten by what follows), then the row's meta dword once the row is done
-            if constexpr (AFF) {
-#pragma unroll
-                for (int x = 0; x + 4 <= NAR; x += 4) *(u32x4u *)(recb + rob + 4 * x) = u32x4u{ar[x], ar[x + 1], ar[x + 2], ar[x + 3]};
-                if constexpr (NAR % 4 == 2) *(u32x2u *)(recb + rob + 4 * (NAR - 2)) = u32x2u{ar[NAR - 2], ar[NAR - 1]};
-                rob += ((min(rem, (uint32_t)CAP) + 3u) >> 2) * 4u;
-            }
-            k0 += CAP;
-            if constexpr (!AFF) {
-                // one store per step: a row that ends here appends its meta dword to the arrow dwords
-                // (the dword behind a one-dword row is overwritten by the next store)
-                // (a row that goes on stores a dword too many as well: its next step overwrites it)
-                const bool one = k0 >= W && rem <= 16u;
-                *(u32x3u *)(recb + rob) = u32x3u{ar[0], one ? meta : ar[1], meta};
-                rob += k0 >= W && rem > 16u ? 12u : 8u;
-            }
-            if (k0 >= W) {
+            nmlo = tab[((next >> 10) & 7u) * 2]; nmhi = tab[((next >> 10) & 7u) * 2 + 1];
+            if (did) {
+                // record: the arrow dwords of this step (stored whole; the tail past the row end is
+                // overwritten by what follows), then the row's meta dword once the row is done
                 if constexpr (AFF) {
-                    *(uint32_t *)(recb + rob) = meta;
-                    rob += 4u;
+    #pragma unroll
+                    for (int x = 0; x + 4 <= NAR; x += 4) *(u32x4u *)(recb + rob + 4 * x) = u32x4u{ar[x], ar[x + 1], ar[x + 2], ar[x + 3]};
+                    if constexpr (NAR % 4 == 2) *(u32x2u *)(recb + rob + 4 * (NAR - 2)) = u32x2u{ar[NAR - 2], ar[NAR - 1]};
+                    rob += ((min(rem, (uint32_t)CAP) + 3u) >> 2) * 4u;
                 }
-                if (rows_left == 0u) {
-                    final_word = lds[fslot * 64 + lane];
-                    finished = true;
+                k0 += CAP;
+                if constexpr (!AFF) {
+                    // one store per step: a row that ends here appends its meta dword to the arrow dwords
+                    // (the dword behind a one-dword row is overwritten by the next store)
+                    // (a row that goes on stores a dword too many as well: its next step overwrites it)
+                    const bool one = k0 >= W && rem <= 16u;
+                    *(u32x3u *)(recb + rob) = u32x3u{ar[0], one ? meta : ar[1], meta};
+                    rob += k0 >= W && rem > 16u ? 12u : 8u;
+                }
+                if (k0 >= W) {
+                    if constexpr (AFF) {
+                        *(uint32_t *)(recb + rob) = meta;
+                        rob += 4u;
+                    }
+                    if (rows_left == 0u) {
+                        final_word = lds[fslot * 64 + lane];
+                        finished = true;
+                    }
                 }
             }
+    };
+    // Four steps per turn on one 16-byte group of the sector; which group is the same for every lane (the loop counter
+    // says it), so the words are named registers, no lane selects anything and the whole wave asks for the next sector
+    // at once, every sixteenth step.
+    for (uint32_t it = 0; it < max_steps && __any(!finished); it += 4) {
+        const uint32_t g = (it >> 2) & 3u;
+        u32x4 A; uint32_t nf;
+        if (g == 0u) { A = R0; nf = R1.x; } else if (g == 1u) { A = R1; nf = R2.x; } else if (g == 2u) { A = R2; nf = R3.x; } else { A = R3; nf = S0.x; }
+        step(A.x, A.y); step(A.y, A.z); step(A.z, A.w); step(A.w, nf);
+        if (g == 3u) {
+            R0 = S0; R1 = S1; R2 = S2; R3 = S3;
+            ws = min(ws + 16u, wcap - 16u);
+            const uint32_t *src = st + ws;
+            S0 = *(const u32x4 *)(src); S1 = *(const u32x4 *)(src + 4); S2 = *(const u32x4 *)(src + 8); S3 = *(const u32x4 *)(src + 12);
         }
     }
-    // the last step may have requested a sector: nothing may reuse R0..R3's registers before it has arrived
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(R0), "+v"(R1), "+v"(R2), "+v"(R3) : : "memory");
     if (live) {
         const int32_t v = (int32_t)(final_word & ~TAGS) - (int32_t)Q * (128 << SH);
         if (v >= UNREACH || !finished) d.status[p] = GBA_PAIR_UNREACHABLE;
@@ -1025,7 +1034,7 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t 
         // entering columns: INFW words carrying the column's base code
         if (nnew <= 3u) {                               // nearly every row: the entering codes sit in the row word itself
             if ((uint32_t)lane < nnew) ring[Wp + lane] = INFW | ((word >> (23u + 3u * (uint32_t)lane)) & 7u);
-            spos += 1u;
+            spos += 1u + cont_words(W, CAP_LINEAR);
         } else {
             for (uint32_t x = lane; x < nnew; x += 64) {
                 uint32_t code;
@@ -1036,7 +1045,7 @@ __global__ __launch_bounds__(64) void k_fill_wide(Dev d, FillConst fc, uint32_t 
                 }
                 ring[Wp + x] = INFW | code;
             }
-            spos += 1u + ((nnew + 4u) >> 3);
+            spos += 1u + ((nnew + 4u) >> 3) + cont_words(W, CAP_LINEAR);
         }
         __syncthreads();
         // carries into the first chunk: the diagonal predecessor of column 0 and "the cell left of it"
@@ -1171,7 +1180,7 @@ __global__ __launch_bounds__(64) void k_fill_wide_cols(Dev d, FillConst fc, uint
         const uint32_t nnew = tot > Wp ? tot - Wp : 0u;
         if (nnew <= 3u) {                               // nearly every row: the entering codes sit in the row word itself
             if ((uint32_t)lane < nnew) ring[Wp + lane] = INFW | ((word >> (23u + 3u * (uint32_t)lane)) & 7u);
-            spos += 1u;
+            spos += 1u + cont_words(W, CAP_LINEAR);
         } else {
             for (uint32_t x = lane; x < nnew; x += 64) {
                 uint32_t code;
@@ -1182,7 +1191,7 @@ __global__ __launch_bounds__(64) void k_fill_wide_cols(Dev d, FillConst fc, uint
                 }
                 ring[Wp + x] = INFW | code;
             }
-            spos += 1u + ((nnew + 4u) >> 3);
+            spos += 1u + ((nnew + 4u) >> 3) + cont_words(W, CAP_LINEAR);
         }
         __syncthreads();
         uint32_t cdiag = dsh >= 1u && dsh - 1u < Wp ? ring[dsh - 1u] : INFW;
@@ -1331,7 +1340,7 @@ __global__ __launch_bounds__(64) void k_fill_wide_affine(Dev d, FillConst fc, ui
                 ringM[Wp + lane] = INFW | ((word >> (23u + 3u * (uint32_t)lane)) & 7u);
                 ringI[Wp + lane] = INFW;
             }
-            spos += 1u;
+            spos += 1u + cont_words(W, CAP_AFFINE);
         } else {
             for (uint32_t x = lane; x < nnew; x += 64) {
                 uint32_t code;
@@ -1343,7 +1352,7 @@ __global__ __launch_bounds__(64) void k_fill_wide_affine(Dev d, FillConst fc, ui
                 ringM[Wp + x] = INFW | code;
                 ringI[Wp + x] = INFW;
             }
-            spos += 1u + ((nnew + 4u) >> 3);
+            spos += 1u + ((nnew + 4u) >> 3) + cont_words(W, CAP_AFFINE);
         }
         __syncthreads();
         // row 0: the diagonal candidate of cell (0,0) costs exactly 0
@@ -1522,7 +1531,7 @@ __global__ __launch_bounds__(64) void k_fill_quad_affine(Dev d, FillConst fc, ui
                 }
             }
         }
-        if (act) spos += 1u + (nnew > 3u ? (nnew + 4u) >> 3 : 0u);
+        if (act) spos += 1u + (nnew > 3u ? (nnew + 4u) >> 3 : 0u) + cont_words(W, CAP_AFFINE);
         __syncthreads();
         // row 0: the diagonal candidate of cell (0,0) costs exactly 0
         uint32_t cdiag = INFW;
@@ -2881,7 +2890,7 @@ int phase_sizes(gba_ctx *c, Slot &sl, const Dev &d)
         sa = sa > pmax ? sa : pmax; sb = sb > pmax ? sb : pmax;
     }
     hipLaunchKernelGGL(k_meta, dim3((d.n + 255) / 256), dim3(256), 0, sl.s, d, sc.mode, sc.kband_k, sa, sb,
-                       (uint32_t)(UNREACH >> (sc.mode == GBA_MODE_AFFINE ? 6 : 5)));
+                       (uint32_t)(UNREACH >> (sc.mode == GBA_MODE_AFFINE ? 6 : 5)), sc.band, sc.max_band);
     hipLaunchKernelGGL(k_scan3, dim3(1), dim3(SCAN_T), 0, sl.s, d);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(sl.h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, sl.s));

@@ -1,11 +1,10 @@
 """Checks on the generated gfx950 code of the lane-per-pair fill kernels that the source cannot
-express.  k_fill requests the next sector of its guide stream with four global_load_dwordx4 from an
-inline-asm block and waits for them only at the top of the block's NEXT execution; until then the
-sixteen destination registers are in flight and the hardware has no interlock for them.  The
-compiler sees them as ordinary values, so a copy, spill or re-use it inserts between the request
-and the wait would silently carry stale data.  This test disassembles what the build produced and
-fails if it did.  (The assembly is written by blasr_amd.build next to the library, from the same
-source with the same flags.)"""
+express: no register spills (a spilled DP word would pass through memory on every cell), the guide
+stream requested a sector at a time and only at the one place in the loop where the whole wave asks
+together, and the arrow pack of the linear kernel at two instructions per cell (left to itself the
+compiler shifts first and masks with a 32-bit literal, three instructions for every second cell).
+(The assembly is written by blasr_amd.build next to the library, from the same source with the same
+flags.)"""
 import os
 import re
 import subprocess
@@ -41,59 +40,36 @@ def isa():
     return open(build.ISA).read()
 
 
-@pytest.mark.parametrize("name", sorted(KERNELS))
-def test_guide_sector_registers_are_left_alone_while_in_flight(isa, name):
-    lines = _function(isa, KERNELS[name])
-    # the request block: the inline-asm region that holds the four loads
-    blocks, cur = [], None
-    for i, ln in enumerate(lines):
-        if "#ASMSTART" in ln:
-            cur = i
-        elif "#ASMEND" in ln and cur is not None:
-            blocks.append((cur, i)); cur = None
-    req = [(a, b) for a, b in blocks if sum("global_load_dwordx4" in x for x in lines[a:b]) == 4]
-    assert len(req) == 1, "expected exactly one request block in the loop of %s" % name
-    a, b = req[0]
-    body = [x.strip() for x in lines[a:b]]
-    assert body[1].startswith("s_waitcnt vmcnt(0)"), "the block must begin by waiting for the previous request"
-    flight = set()
-    for x in body:
-        if x.startswith("global_load_dwordx4"):
-            flight |= _regs(x.split()[1].rstrip(","))
-    assert len(flight) == 16
-    # the loop: from its header label (the last label before the block that a later branch targets) to that branch
+def _loop(lines):
+    """The instructions between the first loop header label and the last branch back to it."""
     labels = {m.group(1): i for i, ln in enumerate(lines) for m in [re.match(r"(\.LBB\d+_\d+):", ln)] if m}
-    back = [(i, m.group(1)) for i, ln in enumerate(lines) for m in [re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", ln)]
-            if m and labels.get(m.group(1), 1 << 30) < a and i > b]
-    assert back, "no back edge around the request block"
-    head = min(labels[t] for _, t in back)
-    tail = max(i for i, _ in back)
-    # Inside the loop, outside the block:
-    #  - after the request until the end of the loop body nothing may touch the sixteen registers at all;
-    #  - from the loop head to the block (the word pop, which by construction only takes a group whose load was
-    #    waited for three pops earlier) they may only be READ by moves / selects into ONE group of four registers
-    #    (the kernel's group of unread words), never written, stored or copied anywhere else.
-    def insns(rng):
-        for i in rng:
-            ln = lines[i].split(";")[0].strip()
-            if not ln or ln.endswith(":") or ln.startswith("."):
-                continue
-            op, _, rest = ln.partition(" ")
-            toks = [t.strip().split()[0] if t.strip() else "" for t in rest.split(",")]
-            yield i, ln, op, [_regs(t) for t in toks]
-    bad, group = [], set()
-    for i, ln, op, regs in insns(range(b + 1, tail + 1)):
-        if any(r & flight for r in regs):
-            bad.append((i, ln))
-    for i, ln, op, regs in insns(range(head, a)):
-        if not any(r & flight for r in regs):
-            continue
-        if regs[0] & flight or not op.startswith(("v_mov_b32", "v_mov_b64", "v_cndmask_b32")):
-            bad.append((i, ln))
-        else:
-            group |= regs[0]
-    assert not bad, "in-flight guide registers are touched outside the request block:\n" + "\n".join("%d: %s" % x for x in bad)
-    assert len(group) == 4, "the guide registers are copied to more than the one group of four: %s" % sorted(group)
+    head = min(i for i, ln in enumerate(lines) if "Loop Header" in ln)
+    back = [i for i, ln in enumerate(lines) for m in [re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", ln)]
+            if m and labels.get(m.group(1), 1 << 30) <= head and i > head]
+    assert back
+    out = []
+    for ln in lines[head:max(back) + 1]:
+        ln = ln.split(";")[0].strip()
+        if ln and not ln.endswith(":") and not ln.startswith("."):
+            out.append(ln.split()[0])
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(KERNELS))
+def test_guide_stream_is_requested_a_sector_at_a_time_in_one_place(isa, name):
+    ops = _loop(_function(isa, KERNELS[name]))
+    loads = [o for o in ops if o.startswith(("global_load", "flat_load", "buffer_load"))]
+    # four steps per turn of the loop; the sector behind the one in use is asked for in one place: four 16-byte loads
+    assert loads == ["global_load_dwordx4"] * 4, loads
+
+
+def test_arrow_pack_of_the_linear_kernel_is_two_instructions_per_cell(isa):
+    ops = _loop(_function(isa, KERNELS["k_fill<false>"]))
+    cells = ops.count("v_min3_i32")
+    assert cells == 4 * 32                                  # four steps of 32 cell slots
+    assert ops.count("v_bfe_u32") >= cells                  # the arrow of every cell
+    assert ops.count("v_lshl_or_b32") >= cells - 4 * 2      # shifted into its record dword (the first cell of a dword is a move)
+    assert ops.count("v_or3_b32") == 0
 
 
 @pytest.mark.parametrize("name", sorted(KERNELS))
