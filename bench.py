@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 # HBM bytes of one step's fill launches at the default workload, from separate rocprofv3 --pmc passes of
 # this command (profiles/, WRITE_SIZE + 2 x FETCH_SIZE: the gfx950 correction for streamed reads)
-MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 491520): 162497107 * 1024 + 2 * 15922240 * 1024}
+MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 491520): 151606121 * 1024 + 2 * 19548425 * 1024}
 OPS_PER_CELL = {"linear": 8, "affine": 18}         # algorithmic int32 ops per DP cell
 BYTES_PER_CELL = {"linear": 0.25, "affine": 0.75}  # algorithmic traceback bytes per cell
 VALU_PEAK_TOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz int32 lane-ops/s (= half the 157.3 TFLOP/s fp32 vector peak)
@@ -523,7 +523,7 @@ def main():
                                                               "aligned interval) only, as interval (-m 4) output needs"},
                                    "packed_reads": {"gcups": round(h["cells"] / (h["packed_ms_per_step"] / 1e3) / 1e9, 2), "ms_per_step": round(h["packed_ms_per_step"], 3),
                                                     "h2d_gb": round(h["packed_h2d_bytes"] / 1e9, 3), "same_results": h["packed_ok"],
-                                                    "what": "the same batches with the reads 2 bits per base (gba_batch.q_packed), spelt out on the device part by part"},
+                                                    "what": "the same batches with the reads 2 bits per base (gba_batch.q_packed): a quarter of the read bytes cross the link and the kernels read the packed form"},
                                    "from_sequences": {
                                        "what": "the same batches WITHOUT their guide blocks (gba_set_guide_producer): reads and windows in, guides made "
                                                "on the device, refined alignments out; nothing of a guide crosses the link",
