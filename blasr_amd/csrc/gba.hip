@@ -49,7 +49,7 @@ constexpr int32_t UNREACH = 0x20000000;      // unbiased words at or above this 
 constexpr uint32_t MAX_ROWS = 65535;         // keeps biased words inside int32 (see gba_set_scoring)
 constexpr uint32_t MAX_ROWS_AFFINE = 32767;  // affine words carry one more tag bit
 constexpr uint32_t MAX_COLS = 1u << 20;
-constexpr int N_PAIR32 = 18, N_PAIR64 = 5;   // per-pair scratch arrays of 4 and 8 bytes (gba_ctx::b_pair32 / b_pair64)
+constexpr int N_PAIR32 = 18, N_PAIR64 = 6;   // per-pair scratch arrays of 4 and 8 bytes (gba_ctx::b_pair32 / b_pair64)
 // Classes of the lane-per-pair fill kernel: a pair's class is the smallest LDS row buffer
 // (32 << class slots) that holds its widest "shift + width".  Each non-empty class is one launch.
 constexpr int NCLS = 5;                      // lane-per-pair classes of 32, 64, 128 slots, then the two wave-per-pair classes
@@ -86,7 +86,8 @@ struct Plan {                 // device -> host after k_scan3 / k_plan
     uint32_t cls_count[NCLS + 1];
     uint32_t cls_base[NCLS + 1];
     uint32_t n_ok;
-    uint32_t pad;
+    uint32_t pool_fail;           // pairs whose blocks found no room (see blk_region_start)
+    unsigned long long pool_used; // blocks handed out from the overflow pool
 };
 
 struct Dev {                  // per-batch device state, SoA per pair
@@ -117,6 +118,9 @@ struct Dev {                  // per-batch device state, SoA per pair
     uint8_t *tcodes;
     uint32_t *rec;            // traceback records, per DP row: ceil(width/16) dwords of 2-bit arrows, then one meta dword
     gba_block *blk_scratch;
+    uint64_t *blk_end;             // per pair: one past the last block of the region that holds its refined blocks
+    uint64_t blk_pool_off, blk_pool_cap;    // the overflow pool behind the pairs' regions: first block, blocks
+    uint32_t blk_div;              // a pair's region holds rows / blk_div + 31 blocks
 };
 
 struct FillConst {
@@ -163,6 +167,46 @@ __device__ __forceinline__ uint32_t query_code(const uint8_t *q_arena, const uin
 __device__ __forceinline__ uint64_t align16(uint64_t x) { return (x + 15) & ~uint64_t(15); }
 // code arrays of a pair start 16-byte aligned and are followed by at least 33 spare bytes
 __device__ __forceinline__ uint64_t tc_offset(const Dev &d, uint32_t p) { return align16(d.col_off[p] + 48ull * p); }
+
+// Block scratch of the tracebacks.  A refined alignment of Q rows can have Q blocks, but has about one per eight rows
+// on 15 %-error reads; a pair's own region therefore holds rows / blk_div + 31 blocks (regions follow from the scan of the
+// rows: disjoint, no offsets of their own), written from its end backwards.  A pair that needs more takes a region of
+// full size from the pool behind the regions (one atomic add), moves what it has written there and goes on; when the
+// pool is used up the pair gives up (Plan::pool_fail) and the host runs the batch again with blk_div = 1 (regions of
+// rows + 31 blocks, which always suffice).  Readers find a pair's blocks at blk_end[p] - n_blk.
+__device__ __forceinline__ uint64_t blk_region_start(const Dev &d, uint32_t p) { return d.row_off[p] / d.blk_div + 32ull * p; }
+__device__ __forceinline__ uint64_t blk_region_end(const Dev &d, uint32_t p) { return (d.row_off[p] + d.rows[p]) / d.blk_div + 32ull * p + 31ull; }
+
+// The writer's side: `outp` points at the block written last (a region's end at first), `lowp` at the region's start.
+struct BlkOut {
+    uint32_t *outp, *lowp;
+    uint64_t end;
+    bool room;
+};
+__device__ __forceinline__ BlkOut blk_out_begin(const Dev &d, uint32_t p)
+{
+    BlkOut o;
+    o.end = blk_region_end(d, p);
+    o.outp = (uint32_t *)(d.blk_scratch + o.end);
+    o.lowp = (uint32_t *)(d.blk_scratch + blk_region_start(d, p));
+    o.room = true;
+    return o;
+}
+// called by ONE lane when outp == lowp and another block is to be written: `have` blocks are in the region
+__device__ __forceinline__ void blk_out_spill(gba_block *scratch, Plan *plan, uint64_t pool_off, uint64_t pool_cap, BlkOut &o, uint32_t rows, uint32_t have)
+{
+    const unsigned long long at = pool_cap ? atomicAdd(&plan->pool_used, (unsigned long long)rows) : 0ull;
+    if (pool_cap && at + rows <= pool_cap) {
+        const uint64_t nend = pool_off + at + rows;
+        uint32_t *dst = (uint32_t *)(scratch + nend) - 3u * have;
+        const uint32_t *src = o.lowp;
+        for (uint32_t x = 0; x < 3u * have; x++) dst[x] = src[x];
+        o.outp = dst; o.lowp = (uint32_t *)(scratch + (nend - rows)); o.end = nend;
+    } else {
+        o.room = false;
+        atomicAdd(&plan->pool_fail, 1u);
+    }
+}
 
 // ---------------------------------------------------------------- k_meta
 // DP region of each pair.  Guided modes: from the first block's start to the last block's end
@@ -677,7 +721,7 @@ __global__ __launch_bounds__(SCAN_T) void k_plan(Dev d, int ncls, int has_wide, 
     }
     uint64_t tot;
     block_excl_scan(cells, sm, &tot);
-    if (threadIdx.x == 0) { d.plan->total_rec_dwords = carry; d.plan->total_cells = tot; }
+    if (threadIdx.x == 0) { d.plan->total_rec_dwords = carry; d.plan->total_cells = tot; d.plan->pool_used = 0; d.plan->pool_fail = 0; }
 }
 
 // ---------------------------------------------------------------- k_fill
@@ -1669,7 +1713,7 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
     const uint32_t *tc4 = (const uint32_t *)(d.tcodes + tc_offset(d, p));   // 4 column codes per dword
     const uint8_t *twin8 = (const uint8_t *)twin;
     constexpr uint32_t CSHIFT = AFF ? 2u : 4u, CMASK = AFF ? 3u : 15u, BITS = AFF ? 8u : 2u;
-    uint32_t *outp = (uint32_t *)(d.blk_scratch + d.row_off[p] + Q + 1);     // end of the pair's block scratch
+    BlkOut bo = blk_out_begin(d, p);
     uint32_t i = Q, j = T, lo = d.lo_last[p], nb = 0, run = 0;
     uint32_t nM = 0, ndiag = 0, nopen = 0;
     int32_t score = 0;
@@ -1767,7 +1811,11 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
             if (nx > 0) { const int32_t v = sub[25 + si]; xs0 += dmove ? v : 0; }
             if (nx > 1) { const int32_t v = sub[50 + si]; xs1 += dmove ? v : 0; }
             ndiag += dmove ? 1u : 0u;
-            if (gmove && run != 0u) { outp -= 3; outp[0] = i; outp[1] = j; outp[2] = run; nb++; }
+            if (gmove && run != 0u) {
+                if (bo.outp == bo.lowp && bo.room) blk_out_spill(d.blk_scratch, d.plan, d.blk_pool_off, d.blk_pool_cap, bo, Q + 1u, nb);
+                if (bo.room) { bo.outp -= 3; bo.outp[0] = i; bo.outp[1] = j; bo.outp[2] = run; }
+                nb++;
+            }
             run = dmove ? run + 1u : gmove ? 0u : run;
             nopen += gmove && prev_op != mv ? 1u : 0u;
             prev_op = dmove ? 0u : gmove ? mv : prev_op;
@@ -1782,13 +1830,18 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
     score += pend;
     if (!live) return;
     gba_pair_result &R = res[p];
-    if (run) { outp -= 3; outp[0] = i; outp[1] = j; outp[2] = run; nb++; }
+    if (run) {
+        if (bo.outp == bo.lowp && bo.room) blk_out_spill(d.blk_scratch, d.plan, d.blk_pool_off, d.blk_pool_cap, bo, Q + 1u, nb);
+        if (bo.room) { bo.outp -= 3; bo.outp[0] = i; bo.outp[1] = j; bo.outp[2] = run; }
+        nb++;
+    }
+    d.blk_end[p] = bo.end;
     if (!ok) { d.status[p] = GBA_PAIR_UNREACHABLE; return; }
     // every row is consumed by a diagonal or an up move, every column by a diagonal or a left move
     const uint32_t nI = Q - ndiag, nD = T - ndiag;
     score += gap_score(tc_.affine, tc_.ins, tc_.del, tc_.aopen, tc_.aext, nI, nD, nopen);
     R.n_blk = nb; R.score = score;
-    d.span[p] = nb;
+    d.span[p] = bo.room ? nb : 0u;            // no room: nothing of this pair is read, the batch is run again
     R.n_match = nM; R.n_mismatch = ndiag - nM; R.n_ins = nI; R.n_del = nD;
     if (nx > 0) R.extra_score[0] = xs0 + gap_score(tc_.xaffine[0], tc_.xins[0], tc_.xdel[0], tc_.xaopen[0], tc_.xaext[0], nI, nD, nopen);
     if (nx > 1) R.extra_score[1] = xs1 + gap_score(tc_.xaffine[1], tc_.xins[1], tc_.xdel[1], tc_.xaopen[1], tc_.xaext[1], nI, nD, nopen);
@@ -1825,7 +1878,14 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
     const uint32_t *rec = d.rec + d.rec_off[p];
     const uint8_t *tc = d.tcodes + tc_offset(d, p);
     const uint8_t *tcw8 = (const uint8_t *)tcw;
-    uint32_t *outp = (uint32_t *)(d.blk_scratch + d.row_off[p] + Q + 1);     // end of the pair's block scratch
+    BlkOut bo = blk_out_begin(d, p);                    // only lane 0's copy is used
+    // one more block (i, j, run): lane 0 stores it
+    auto put = [&](uint32_t bi_, uint32_t bj_, uint32_t brun, uint32_t have) {
+        if (lane == 0) {
+            if (bo.outp == bo.lowp && bo.room) blk_out_spill(d.blk_scratch, d.plan, d.blk_pool_off, d.blk_pool_cap, bo, Q + 1u, have);
+            if (bo.room) { bo.outp -= 3; bo.outp[0] = bi_; bo.outp[1] = bj_; bo.outp[2] = brun; }
+        }
+    };
     // The walk is wave-uniform: every lane follows the same path, LDS values are made scalar right
     // after they are read, so the whole state machine runs on the scalar unit; only lane 0 stores.
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)v); };
@@ -1911,8 +1971,7 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
                     }
                     if (gap != 0u) {
                         if (run) {
-                            outp -= 3;
-                            if (lane == 0) { outp[0] = i; outp[1] = j; outp[2] = run; }
+                            put(i, j, run, nb);
                             nb++; run = 0;
                         }
                         nopen += prev_op != gap ? 1u : 0u;
@@ -1967,8 +2026,7 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
                 run++; ndiag++; prev_op = 0;
             } else {
                 if (run) {
-                    outp -= 3;
-                    if (lane == 0) { outp[0] = i; outp[1] = j; outp[2] = run; }
+                    put(i, j, run, nb);
                     nb++; run = 0;
                 }
                 nopen += prev_op != mv ? 1u : 0u;
@@ -1993,14 +2051,15 @@ __global__ __launch_bounds__(64) void k_traceback_wide(Dev d, TbConst tc_, gba_p
         lane_x1 += __shfl_xor(lane_x1, o, 64);
     }
     score += lane_score; xs0 += lane_x0; xs1 += lane_x1;
-    if (run) { outp -= 3; if (lane == 0) { outp[0] = i; outp[1] = j; outp[2] = run; } nb++; }
+    if (run) { put(i, j, run, nb); nb++; }
     if (lane != 0) return;
+    d.blk_end[p] = bo.end;
     gba_pair_result &R = res[p];
     if (!ok) { d.status[p] = GBA_PAIR_UNREACHABLE; return; }
     const uint32_t nI = (LOCAL ? ei - i : Q) - ndiag, nD = (LOCAL ? ej - j : T) - ndiag;
     score += gap_score(tc_.affine, tc_.ins, tc_.del, tc_.aopen, tc_.aext, nI, nD, nopen);
     R.n_blk = nb; R.score = score;
-    d.span[p] = nb;
+    d.span[p] = bo.room ? nb : 0u;            // no room: nothing of this pair is read, the batch is run again
     R.n_match = nM; R.n_mismatch = ndiag - nM; R.n_ins = nI; R.n_del = nD;
     if (nx > 0) R.extra_score[0] = xs0 + gap_score(tc_.xaffine[0], tc_.xins[0], tc_.xdel[0], tc_.xaopen[0], tc_.xaext[0], nI, nD, nopen);
     if (nx > 1) R.extra_score[1] = xs1 + gap_score(tc_.xaffine[1], tc_.xins[1], tc_.xdel[1], tc_.xaopen[1], tc_.xaext[1], nI, nD, nopen);
@@ -2063,7 +2122,7 @@ __global__ __launch_bounds__(SCAN_T) void k_scan1(Dev d, uint64_t *needed)
         }
         carry += tot;
     }
-    if (threadIdx.x == 0) *needed = carry;
+    if (threadIdx.x == 0) { *needed = carry; needed[2] += d.plan->pool_fail; }
 }
 
 // One block per pair: completes the pair's result record (the aligned interval included) and, when
@@ -2076,7 +2135,7 @@ __global__ __launch_bounds__(256) void k_emit(Dev d, gba_pair_result *res, gba_b
     const uint64_t off = d.word_off[p];
     const uint32_t nb = st == GBA_PAIR_OK ? d.span[p] : 0u;
     const bool fits = !want_blocks || off + nb <= capacity;
-    const gba_block *src = d.blk_scratch + d.row_off[p] + (d.Q[p] + 1 - nb);
+    const gba_block *src = d.blk_scratch + (nb ? d.blk_end[p] - nb : 0ull);
     if (threadIdx.x == 0) {
         gba_pair_result &R = res[p];
         R.status = st;
@@ -2147,7 +2206,7 @@ __global__ __launch_bounds__(64) void k_cigar(Dev d, uint32_t flags, const uint6
         out = ops + o;
     }
     const uint32_t Q = d.Q[p];
-    const gba_block *bl = d.blk_scratch + d.row_off[p] + (Q + 1 - nb);
+    const gba_block *bl = d.blk_scratch + (d.blk_end[p] - nb);
     const uint8_t *tc = d.tcodes + tc_offset(d, p) + 1;      // tc[x]: code + 1 of the target base x columns after t_pos
     uint8_t *qc = (uint8_t *)(d.rec + d.rec_off[p]);         // qc[x]: the same for the query base x rows after q_pos
     const bool seqm = (flags & GBA_CIGAR_SEQ_MATCH) != 0, adj = (flags & GBA_CIGAR_ADJACENT_INDELS) != 0;
@@ -2722,7 +2781,10 @@ static __device__ __align__(256) unsigned char scratch[GBA_NOALLOC_SCRATCH_BYTES
 
 }  // namespace
 
-constexpr int NSLOT = 2;      // a large batch is run in parts that alternate between two slots, staggered, so that one
+#ifndef GBA_NSLOT
+#define GBA_NSLOT 2
+#endif
+constexpr int NSLOT = GBA_NSLOT;      // a large batch is run in parts that alternate between two slots, staggered, so that one
                               // part's guide construction and traceback run under the other part's DP fill
 constexpr int NAUXS = 2;      // auxiliary streams per slot (wider classes run beside the bulk class)
 
@@ -2757,6 +2819,11 @@ struct gba_ctx {
     // k_sdp_match: target positions indexed at a time, at most (env GBA_SDP_TILE; power of two, 1024..16384), and hash slots
     // per indexed position (env GBA_SDP_SLOTS: 2 or 4).  Measured on 32 768 pairs of 10 kb, whole guide production, 512
     // threads per pair: 2048 x 4: 9.7 ms; 4096 x 2: 13.1; 4096 x 4: 14.1; 8192 x 2: 16.3
+    // block scratch of the tracebacks (blk_region_start): a pair's own region holds rows / blk_div + 31 blocks (env GBA_BLK_DIV,
+    // 1 = room for the worst case, no pool), the overflow pool total rows / blk_pool_div blocks plus one pair of the largest
+    // size (env GBA_BLK_POOL_DIV); blk_div_now is what the running batch uses (1 when it is being repeated)
+    uint32_t blk_div = 3, blk_pool_div = 8, blk_div_now = 3;
+    uint32_t scratch_retries = 0;    // batches repeated with full-size block scratch
     uint32_t sdp_queue = 1024;       // hits queued per tile (env GBA_SDP_QUEUE, 64..16384)
     uint32_t sdp_tile_max = 2048;
     uint32_t sdp_slots_per_pos = 4;
@@ -2873,7 +2940,7 @@ Dev sub_dev(const Dev &g, uint32_t p0, uint32_t cnt, Slot &sl)
     d.status += p0; d.qS += p0; d.tS += p0; d.Q += p0; d.T += p0; d.rows += p0; d.cols += p0; d.wcap += p0;
     d.span += p0; d.lo_last += p0; d.cls += p0; d.order += p0; d.recdw += p0;
     d.end_i += p0; d.end_j += p0; d.end_lo += p0; d.end_ptr += p0;
-    d.row_off += p0; d.col_off += p0; d.word_off += p0; d.rec_off += p0; d.ncells += p0; d.dp_score += p0;
+    d.row_off += p0; d.col_off += p0; d.word_off += p0; d.rec_off += p0; d.ncells += p0; d.dp_score += p0; d.blk_end += p0;
     d.plan = (Plan *)sl.b_plan.ptr;
     return d;
 }
@@ -2906,7 +2973,10 @@ int phase_guide(gba_ctx *c, Slot &sl, Dev &d)
     const uint64_t cols = sl.h_plan->total_cols;
     { int rc = ensure(c, sl.b_guide, (size_t)(sl.h_plan->total_words + 16) * 4); if (rc) return rc; }
     { int rc = ensure(c, sl.b_tc, (size_t)(cols + 48ull * d.n + 64 + 2 * ARENA_SLACK)); if (rc) return rc; }
-    { int rc = ensure(c, sl.b_blk, (size_t)(sl.rows + 4) * sizeof(gba_block)); if (rc) return rc; }
+    d.blk_div = c->blk_div_now;
+    d.blk_pool_off = sl.rows / d.blk_div + 32ull * d.n + 32;
+    d.blk_pool_cap = d.blk_div > 1u ? sl.rows / c->blk_pool_div + MAX_ROWS + 64 : 0;
+    { int rc = ensure(c, sl.b_blk, (size_t)(d.blk_pool_off + d.blk_pool_cap + 4) * sizeof(gba_block)); if (rc) return rc; }
     d.stream = (uint32_t *)sl.b_guide.ptr;
     d.tcodes = (uint8_t *)sl.b_tc.ptr + ARENA_SLACK;
     d.blk_scratch = (gba_block *)sl.b_blk.ptr;
@@ -3189,7 +3259,29 @@ int finish_part(gba_ctx *c, HostIO &io, Slot &sl)
 // addresses): the inputs of part h + 1 are copied in while part h is being launched, and a part's
 // blocks are packed and copied out one part later, once its block count has been read back, so
 // copies in both directions run beside the kernels of the parts around them.
+constexpr int RETRY_FULL_SCRATCH = 1 << 20;     // internal: never leaves run_device
+
+int run_device_once(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io);
+
 int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nullptr)
+{
+    HostIO fresh;
+    if (io) fresh = *io;
+    c->blk_div_now = c->blk_div;
+    int rc = run_device_once(c, b, out, io);
+    if (rc == RETRY_FULL_SCRATCH) {
+        // rare: alignments with far more blocks than rows / blk_div, more of them than the pool takes
+        if (io) *io = fresh;
+        c->blk_div_now = 1;
+        c->scratch_retries++;
+        rc = run_device_once(c, b, out, io);
+        c->blk_div_now = c->blk_div;
+        if (rc == RETRY_FULL_SCRATCH) rc = GBA_E_HIP;    // cannot happen: full-size regions take every alignment
+    }
+    return rc;
+}
+
+int run_device_once(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io)
 {
     const uint32_t n = b->n_pairs;
     const bool cig = io ? io->d_cigoff != nullptr : out->cigar_ops != nullptr;
@@ -3204,7 +3296,7 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
     }
     for (int i = 0; i < N_PAIR32; i++) { int rc = ensure(c, c->b_pair32[i], (size_t)n * 4); if (rc) return rc; }
     for (int i = 0; i < N_PAIR64; i++) { int rc = ensure(c, c->b_pair64[i], (size_t)n * 8); if (rc) return rc; }
-    { int rc = ensure(c, c->b_needed, 16); if (rc) return rc; }
+    { int rc = ensure(c, c->b_needed, 32); if (rc) return rc; }
     for (auto &sl : c->slot) { int rc = ensure(c, sl.b_plan, sizeof(Plan)); if (rc) return rc; }
     Dev g;
     memset(&g, 0, sizeof(g));
@@ -3235,6 +3327,8 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
     g.row_off = (uint64_t *)c->b_pair64[0].ptr; g.col_off = (uint64_t *)c->b_pair64[1].ptr;
     g.rec_off = (uint64_t *)c->b_pair64[2].ptr; g.ncells = (uint64_t *)c->b_pair64[3].ptr;
     g.word_off = (uint64_t *)c->b_pair64[4].ptr;
+    g.blk_end = (uint64_t *)c->b_pair64[5].ptr;
+    g.blk_div = c->blk_div_now;
     const bool timing = (c->flags & GBA_FLAG_TIMING) != 0;
     uint32_t parts = 1;
     if (!c->fixed_on && c->part_pairs && n > c->part_pairs + c->part_pairs / 15) {
@@ -3263,10 +3357,10 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
         }
     }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    HIPCHK(c, hipMemsetAsync(needed, 0, 16, s));
-    if (parts > 1) {                                   // the second slot's stream starts after the batch's inputs are ready
+    HIPCHK(c, hipMemsetAsync(needed, 0, 32, s));
+    if (parts > 1) {                                   // the other slots' streams start after the batch's inputs are ready
         HIPCHK(c, hipEventRecord(c->slot[0].ev_fork, s));
-        HIPCHK(c, hipStreamWaitEvent(c->slot[1].s, c->slot[0].ev_fork, 0));
+        for (int x = 1; x < NSLOT; x++) HIPCHK(c, hipStreamWaitEvent(c->slot[x].s, c->slot[0].ev_fork, 0));
     }
     for (uint32_t h = 0; h < parts; h++) {
         Slot &sl = c->slot[h % NSLOT];
@@ -3305,13 +3399,15 @@ int run_device(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io = nu
         HIPCHK(c, hipEventRecord(sl.ev_done, sl.s));
     }
     if (io) { int rc = finish_part(c, *io, c->slot[(parts - 1) % NSLOT]); if (rc) return rc; }
-    if (parts > 1) HIPCHK(c, hipStreamWaitEvent(s, c->slot[1].ev_done, 0));
-    HIPCHK(c, hipMemcpyAsync(c->h_needed, needed, 16, hipMemcpyDeviceToHost, s));
+    for (int x = 1; x < NSLOT; x++)
+        if (used[x]) HIPCHK(c, hipStreamWaitEvent(s, c->slot[x].ev_done, 0));
+    HIPCHK(c, hipMemcpyAsync(c->h_needed, needed, 24, hipMemcpyDeviceToHost, s));
     if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (io) HIPCHK(c, hipStreamSynchronize(c->s_out));
     out->blocks_needed = c->h_needed[0];
     out->cigar_needed = cig ? c->h_needed[1] : 0;
+    if (c->h_needed[2]) return RETRY_FULL_SCRATCH;      // some pair's blocks found no room: the caller repeats the batch
     if (timing) {
         // fill: the bulk fill launches of the parts, one after the other (what else runs on the GPU
         // during a launch makes it longer); traceback: from the last fill's end to the last traceback's
@@ -3347,7 +3443,7 @@ int run_sdp(gba_ctx *c, const gba_batch *b, const gba_sdp_params *sp, gba_guides
     hipStream_t s = sl.s;
     const uint32_t per = sdp_part_size(n);
     { int rc = ensure(c, c->b_pair32[0], (size_t)per * 4); if (rc) return rc; }
-    { int rc = ensure(c, c->b_needed, 16); if (rc) return rc; }
+    { int rc = ensure(c, c->b_needed, 32); if (rc) return rc; }
     uint64_t *needed = (uint64_t *)c->b_needed.ptr;
     HIPCHK(c, hipMemsetAsync(needed, 0, 16, s));
     SdpConst k;
@@ -3510,7 +3606,7 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
         if (hipSetDevice(c->device) != hipSuccess) { rc = GBA_E_HIP; break; }
         if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
         else { if (hipStreamCreate(&c->stream) != hipSuccess) { rc = GBA_E_HIP; break; } c->own_stream = true; }
-        if (hipHostMalloc((void **)&c->h_needed, 16) != hipSuccess) { rc = GBA_E_NOMEM; break; }
+        if (hipHostMalloc((void **)&c->h_needed, 32) != hipSuccess) { rc = GBA_E_NOMEM; break; }
         for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rc = GBA_E_HIP; break; }
         if (rc) break;
         {   // this device's copy of the no-allocation scratch (the ctx stays usable without it)
@@ -3528,6 +3624,8 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
             const uint32_t v = (uint32_t)strtoul(e, nullptr, 10);
             if (v >= 256 && v <= 16384 && (v & (v - 1)) == 0) c->sdp_tile_max = v;
         }
+        if (const char *e = getenv("GBA_BLK_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 1024) c->blk_div = (uint32_t)v; }
+        if (const char *e = getenv("GBA_BLK_POOL_DIV")) { const int v = atoi(e); if (v >= 1 && v <= (1 << 20)) c->blk_pool_div = (uint32_t)v; }
         if (const char *e = getenv("GBA_SDP_QUEUE")) { const int v = atoi(e); if (v >= 64 && v <= 16384) c->sdp_queue = (uint32_t)v; }
         if (const char *e = getenv("GBA_SDP_SLOTS")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) c->sdp_slots_per_pos = (uint32_t)v; }
         for (int h = 0; h < NSLOT && !rc; h++) {
@@ -3991,6 +4089,7 @@ int gba_get_timing(gba_ctx *c, gba_timing *t)
 {
     if (!c || !t) return GBA_E_INVALID;
     *t = c->timing;
+    t->scratch_retries = c->scratch_retries;
     return GBA_OK;
 }
 

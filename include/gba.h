@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GBA_VERSION 380   /* major*10000 + minor*100 + patch */
+#define GBA_VERSION 381   /* major*10000 + minor*100 + patch */
 
 /* return codes of the entry points */
 enum {
@@ -227,6 +227,10 @@ typedef struct {
     uint64_t rows;              /* DP rows of the batch */
     uint64_t record_bytes;      /* traceback bytes the fill kernels wrote */
     uint32_t wide_pairs;        /* pairs that ran in the wave-per-pair kernels (band rows too wide for a lane) */
+    uint32_t scratch_retries;   /* since gba_create, with or without GBA_FLAG_TIMING: batches that were run a second time
+                                   because refined alignments had more blocks than the block scratch, sized for about three
+                                   rows per block plus a shared reserve, had room for (the second run has room for a block
+                                   per row; results are those of a single run) */
 } gba_timing;
 
 /* Replaces the per-thread `MappingBuffers mappingBuffers;` (Blasr.cpp:771): device
