@@ -36,6 +36,11 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# A context runs the parts of a batch on a dozen streams (three slots of a main and two auxiliary streams, two copy
+# streams).  With HIP's default of four hardware queues streams share queues and one part's guide construction waits
+# behind another part's fill; the library's callers are told to raise it, and so does this program,
+# before the HIP runtime starts.
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("GBA_BENCH_HW_QUEUES", "16")      # (the GPU boxes export the default, 4)
 sys.path.insert(0, ROOT)
 
 # HBM bytes of one step's fill launches at the default workload, from separate rocprofv3 --pmc passes of
@@ -441,6 +446,9 @@ def main():
                    "cells_per_step_per_gpu": cells_step, "pairs_ok": ok_all, "pairs_total": n * world,
                    "parallelism": "one common read set of %d pairs, reads i = rank (mod %d) per GPU, no collective, results merged in input order" % (n * world, world)},
         "aligned_reads_per_sec": round(n * args.steps * world / dt, 1),
+        "device_memory": {"ctx_bytes": int(tm["device_bytes"]), "part_pipeline_bytes": int(tm["slot_bytes"]),
+                          "scratch_retries": int(tm["scratch_retries"]),
+                          "what": "device memory the context holds after the timed steps (inputs and outputs are the caller's)"},
         "roofline": {
             "bound": "valu-int32", "kernel": kernel,
             "achieved": round(cells_step * ops_cell / fill_s / 1e12, 3), "peak": VALU_PEAK_TOPS,

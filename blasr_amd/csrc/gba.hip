@@ -2782,10 +2782,13 @@ static __device__ __align__(256) unsigned char scratch[GBA_NOALLOC_SCRATCH_BYTES
 }  // namespace
 
 #ifndef GBA_NSLOT
-#define GBA_NSLOT 2
+#define GBA_NSLOT 3
 #endif
-constexpr int NSLOT = GBA_NSLOT;      // a large batch is run in parts that alternate between two slots, staggered, so that one
-                              // part's guide construction and traceback run under the other part's DP fill
+constexpr int NSLOT = GBA_NSLOT;      // a large batch is run in parts that take the slots in turn, staggered, so that one part's guide
+                              // construction and traceback run under the DP fill of the parts around it.  With two slots a part's
+                              // target packing and guide wait for the traceback of the part two before it (the same slot's stream
+                              // and scratch) and the GPU has no fill to run in between (10 - 20 ms per part of 123 k pairs of
+                              // 10 kb); with three the next part's guide is ready long before a fill ends.
 constexpr int NAUXS = 2;      // auxiliary streams per slot (wider classes run beside the bulk class)
 
 // Everything one (half) batch in flight needs of its own.
@@ -2823,6 +2826,9 @@ struct gba_ctx {
     // 1 = room for the worst case, no pool), the overflow pool total rows / blk_pool_div blocks plus one pair of the largest
     // size (env GBA_BLK_POOL_DIV); blk_div_now is what the running batch uses (1 when it is being repeated)
     uint32_t blk_div = 3, blk_pool_div = 8, blk_div_now = 3;
+    // slots of the part pipeline a batch uses (each holds the scratch of one part): batches whose buffers are on the
+    // device (env GBA_SLOTS_DEVICE) and host-buffer batches (env GBA_SLOTS_HOST); 2 .. NSLOT
+    uint32_t slots_device = NSLOT, slots_host = 2;
     uint32_t scratch_retries = 0;    // batches repeated with full-size block scratch
     uint32_t sdp_queue = 1024;       // hits queued per tile (env GBA_SDP_QUEUE, 64..16384)
     uint32_t sdp_tile_max = 2048;
@@ -3342,6 +3348,8 @@ int run_device_once(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io
     hipStream_t s = c->slot[0].s;
     TimeAcc acc;
     bool used[NSLOT] = {};
+    // slots in use: host-buffer batches overlap with those of a second context (HostPipeline) and get by with two
+    const uint32_t ns = io ? c->slots_host : c->slots_device;
 
     if (io) {
         while (c->ev_in.size() < parts) {
@@ -3363,14 +3371,14 @@ int run_device_once(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io
         for (int x = 1; x < NSLOT; x++) HIPCHK(c, hipStreamWaitEvent(c->slot[x].s, c->slot[0].ev_fork, 0));
     }
     for (uint32_t h = 0; h < parts; h++) {
-        Slot &sl = c->slot[h % NSLOT];
+        Slot &sl = c->slot[h % ns];
         const uint32_t first = h * per, cnt = n - first < per ? n - first : per;
         Dev d = sub_dev(g, first, cnt, sl);
         if (io) HIPCHK(c, hipStreamWaitEvent(sl.s, c->ev_in[h], 0));
         int rc = phase_sizes(c, sl, d); if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(sl.s));         // the sizes are here, and the slot's previous part has completed
-        if (timing && used[h % NSLOT]) { rc = fold_timing(c, sl, acc); if (rc) return rc; }
-        used[h % NSLOT] = true;
+        if (timing && used[h % ns]) { rc = fold_timing(c, sl, acc); if (rc) return rc; }
+        used[h % ns] = true;
         rc = phase_guide(c, sl, d); if (rc) return rc;
         rc = phase_fill(c, sl, d, res + first, (uint32_t)NAUXS); if (rc) return rc;
         if (io && !io->all_ahead && h + 1 < parts) {       // the next part's inputs travel while this part runs
@@ -3379,7 +3387,7 @@ int run_device_once(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io
         }
         if (cig) hipLaunchKernelGGL(k_cigar<false>, dim3(d.n), dim3(64), 0, sl.s, d, out->cigar_flags, (const uint64_t *)nullptr, (uint32_t *)nullptr, 0ull);
         // block (and operation) offsets continue where the part before stopped
-        if (h > 0) HIPCHK(c, hipStreamWaitEvent(sl.s, c->slot[(h - 1) % NSLOT].ev_scan, 0));
+        if (h > 0) HIPCHK(c, hipStreamWaitEvent(sl.s, c->slot[(h - 1) % ns].ev_scan, 0));
         hipLaunchKernelGGL(k_scan1, dim3(1), dim3(SCAN_T), 0, sl.s, d, needed);
         if (cig) hipLaunchKernelGGL(k_scan_ops, dim3(1), dim3(SCAN_T), 0, sl.s, d, needed + 1, cig_off + first);
         HIPCHK(c, hipEventRecord(sl.ev_scan, sl.s));
@@ -3388,7 +3396,7 @@ int run_device_once(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io
             HIPCHK(c, hipMemcpyAsync(sl.h_cnt, needed, 16, hipMemcpyDeviceToHost, sl.s));
             HIPCHK(c, hipEventRecord(sl.ev_cnt, sl.s));
             HIPCHK(c, hipEventRecord(sl.ev_done, sl.s));
-            if (h > 0) { rc = finish_part(c, *io, c->slot[(h - 1) % NSLOT]); if (rc) return rc; }
+            if (h > 0) { rc = finish_part(c, *io, c->slot[(h - 1) % ns]); if (rc) return rc; }
             continue;
         }
         hipLaunchKernelGGL(k_emit, dim3(d.n), dim3(256), 0, sl.s, d, res + first, out->blocks, out->blocks_capacity, want_blocks ? 1 : 0);
@@ -3398,7 +3406,7 @@ int run_device_once(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(sl.ev_done, sl.s));
     }
-    if (io) { int rc = finish_part(c, *io, c->slot[(parts - 1) % NSLOT]); if (rc) return rc; }
+    if (io) { int rc = finish_part(c, *io, c->slot[(parts - 1) % ns]); if (rc) return rc; }
     for (int x = 1; x < NSLOT; x++)
         if (used[x]) HIPCHK(c, hipStreamWaitEvent(s, c->slot[x].ev_done, 0));
     HIPCHK(c, hipMemcpyAsync(c->h_needed, needed, 24, hipMemcpyDeviceToHost, s));
@@ -3624,6 +3632,8 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
             const uint32_t v = (uint32_t)strtoul(e, nullptr, 10);
             if (v >= 256 && v <= 16384 && (v & (v - 1)) == 0) c->sdp_tile_max = v;
         }
+        if (const char *e = getenv("GBA_SLOTS_DEVICE")) { const int v = atoi(e); if (v >= 2 && v <= NSLOT) c->slots_device = (uint32_t)v; }
+        if (const char *e = getenv("GBA_SLOTS_HOST")) { const int v = atoi(e); if (v >= 2 && v <= NSLOT) c->slots_host = (uint32_t)v; }
         if (const char *e = getenv("GBA_BLK_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 1024) c->blk_div = (uint32_t)v; }
         if (const char *e = getenv("GBA_BLK_POOL_DIV")) { const int v = atoi(e); if (v >= 1 && v <= (1 << 20)) c->blk_pool_div = (uint32_t)v; }
         if (const char *e = getenv("GBA_SDP_QUEUE")) { const int v = atoi(e); if (v >= 64 && v <= 16384) c->sdp_queue = (uint32_t)v; }
@@ -4090,6 +4100,20 @@ int gba_get_timing(gba_ctx *c, gba_timing *t)
     if (!c || !t) return GBA_E_INVALID;
     *t = c->timing;
     t->scratch_retries = c->scratch_retries;
+    uint64_t bytes = 0;
+    for (auto &b : c->b_pair32) bytes += b.cap;
+    for (auto &b : c->b_pair64) bytes += b.cap;
+    Buf *bs[] = {&c->b_ref, &c->b_refm, &c->s_trc, &c->b_needed,
+                 &c->s_q, &c->s_t, &c->s_blk, &c->s_qoff, &c->s_toff, &c->s_boff, &c->s_qlen, &c->s_tlen,
+                 &c->s_nblk, &c->s_res, &c->s_cigoff, &c->s_gout, &c->s_prof};
+    for (Buf *b : bs) bytes += b->cap;
+    for (auto &b : c->kb) bytes += b.cap;
+    t->slot_bytes = 0;
+    for (auto &sl : c->slot) {
+        Buf *sb[] = {&sl.b_plan, &sl.b_guide, &sl.b_tc, &sl.b_rec, &sl.b_blk, &sl.b_out, &sl.b_cig};
+        for (Buf *b : sb) { bytes += b->cap; t->slot_bytes += b->cap; }
+    }
+    t->device_bytes = bytes;
     return GBA_OK;
 }
 

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GBA_VERSION 381   /* major*10000 + minor*100 + patch */
+#define GBA_VERSION 382   /* major*10000 + minor*100 + patch */
 
 /* return codes of the entry points */
 enum {
@@ -231,6 +231,10 @@ typedef struct {
                                    because refined alignments had more blocks than the block scratch, sized for about three
                                    rows per block plus a shared reserve, had room for (the second run has room for a block
                                    per row; results are those of a single run) */
+    uint64_t device_bytes;      /* with or without GBA_FLAG_TIMING: device memory the ctx holds now (grow-only scratch of all
+                                   kinds, the resident reference, device copies of host batches) ... */
+    uint64_t slot_bytes;        /* ... of which the scratch of the part pipeline (guide stream, target codes, traceback
+                                   records, block scratch; three parts in flight) */
 } gba_timing;
 
 /* Replaces the per-thread `MappingBuffers mappingBuffers;` (Blasr.cpp:771): device

@@ -27,7 +27,7 @@ def test_exports_match_header():
 def test_version_and_strerror():
     from blasr_amd import _lib
     L = _lib.lib()
-    assert L.gba_version() == 381
+    assert L.gba_version() == 382
     assert L.gba_strerror(0) == b"ok"
     assert b"arena" in L.gba_strerror(_lib.E_NOSPACE)
     assert b"unknown" in L.gba_strerror(12345)
