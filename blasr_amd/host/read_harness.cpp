@@ -134,6 +134,8 @@ size_t PhaseC(const Batch &B, uint32_t K, uint32_t r0, uint32_t r1, uint64_t rea
 
 int main(int argc, char **argv)
 {
+    // before the HIP runtime starts: a context runs a batch's parts on a dozen streams, HIP's default is four hardware queues
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     uint32_t reads = 16384, K = 10, read_len = 10000, jitter = 0, batches = 4, threads = 0;
     uint64_t ref_len = 64444167, seed = 4000;
     double n_frac = 0.01;
