@@ -45,7 +45,7 @@ sys.path.insert(0, ROOT)
 
 # HBM bytes of one step's fill launches at the default workload, from separate rocprofv3 --pmc passes of
 # this command (profiles/, WRITE_SIZE + 2 x FETCH_SIZE: the gfx950 correction for streamed reads)
-MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 491520): 151606121 * 1024 + 2 * 19548425 * 1024}
+MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 491520): 147829239 * 1024 + 2 * 19575698 * 1024}
 OPS_PER_CELL = {"linear": 8, "affine": 18}         # algorithmic int32 ops per DP cell
 BYTES_PER_CELL = {"linear": 0.25, "affine": 0.75}  # algorithmic traceback bytes per cell
 VALU_PEAK_TOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz int32 lane-ops/s (= half the 157.3 TFLOP/s fp32 vector peak)
@@ -405,6 +405,23 @@ def main():
     res = out_pairs.cpu().numpy().view(_lib.PAIR_RESULT_DT)
     tm = ctx.timing()
     cells_step, rec_bytes = int(tm["cells"]), int(tm["record_bytes"])
+    # The fill kernel with the GPU to itself: ONE part of the batch (what the library cuts large batches into), so no
+    # other part's guide construction, traceback or fill runs beside its launches; after the timed region, not in `value`.
+    alone = None
+    part = 122880
+    if rank == 0 and n > part + part // 15 and cigar is None:
+        sub = dict(dbatch, n_pairs=part)
+        for k_ in ("q_off", "q_len", "t_off", "t_len", "blk_off", "n_blk", "t_rc"):
+            if sub.get(k_) is not None:
+                sub[k_] = sub[k_][:part]
+        for _ in range(2):
+            rc_a, _needed = ctx.refine_device(sub, out_pairs, out_blocks)
+        ta = ctx.timing()
+        if rc_a == 0 and ta["fill_ms"] > 0:
+            alone = {"pairs": part, "fill_ms": round(float(ta["fill_ms"]), 3), "cells": int(ta["cells"]),
+                     "achieved": round(int(ta["cells"]) * OPS_PER_CELL[mode] / (ta["fill_ms"] * 1e-3) / 1e12, 3),
+                     "frac": round(int(ta["cells"]) * OPS_PER_CELL[mode] / (ta["fill_ms"] * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4),
+                     "what": "the same kernel on one part of the batch run alone (in the step its launches share the GPU with the other parts' guide construction, tracebacks and fills)"}
     n_ok = int((res["status"] == 0).sum())
     cells_all, ok_all = cells_step, n_ok
     if world > 1:
@@ -456,6 +473,7 @@ def main():
             "ops_per_cell": ops_cell, "fill_ms": round(fill_s * 1e3, 3),     # bulk fill launches of a step, summed (HIP events)
             "fill_gcups": round(cells_step / fill_s / 1e9, 2),
             "traffic": traffic,
+            "alone": alone,
         },
         "roofline_hbm": {
             "bound": "hbm", "kernel": kernel,
