@@ -1685,17 +1685,20 @@ __global__ __launch_bounds__(64) void k_fill_quad_affine(Dev d, FillConst fc, ui
 #ifndef GBA_TB_TSOON
 #define GBA_TB_TSOON 6
 #endif
-constexpr int TB_RW = 64, TB_TW = 12, TB_TSOON = GBA_TB_TSOON;
+constexpr int TB_RW = 64, TB_RW_FEW = 192, TB_TW = 12, TB_TSOON = GBA_TB_TSOON;
 #ifndef GBA_TB_LANES
 #define GBA_TB_LANES 64
 #endif
 constexpr int TB_LANES = GBA_TB_LANES;      // pairs per wave: the walk is a dependent chain, more waves hide more of it
 
-template <bool AFF>
+// RW: record dwords per lane in the window.  An affine row of 33 cells is ten dwords, so 64 dwords are five rows between
+// refills and a walk of few pairs (one wave per CU or two, nothing to hide the refill behind) spends half its time on
+// them; such launches take 192 dwords (TB_RW_FEW), which at 52 KB of LDS a wave is no way to run a full batch.
+template <bool AFF, int RW = TB_RW>
 __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_pair_result *res, uint32_t first, uint32_t count)
 {
     __shared__ int32_t sub[25 * (1 + GBA_MAX_EXTRA)];     // the stats scorer's matrix, then the extra scorers'
-    __shared__ uint32_t rwin[TB_RW * TB_LANES];
+    __shared__ uint32_t rwin[RW * TB_LANES];
     __shared__ uint32_t twin[TB_TW * TB_LANES];
     if (threadIdx.x < 25) {
         sub[threadIdx.x] = tc_.sub[threadIdx.x];
@@ -1739,7 +1742,7 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
         if (!__any(active)) break;
         {
             // linear pairs of the lane classes have rows of at most 8 arrow dwords: always inside the window
-            const int32_t look = AFF ? (int32_t)min(n + 1u, (uint32_t)TB_RW - 16u) : (int32_t)n + 1;
+            const int32_t look = AFF ? (int32_t)min(n + 1u, (uint32_t)RW - 16u) : (int32_t)n + 1;
             const int32_t jd = (int32_t)(j >> 2) - 1;
             if (__any(active && (ptr - look < rb || jd < tb))) {
                 // The walk is bound by these scattered reads (every lane in a record of its own,
@@ -1749,11 +1752,11 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
                 // when a lane will leave it within the next ~24 columns.
                 const bool codes = __any(active && jd - TB_TSOON < tb);
                 if (active) {
-                    rb = ptr - (TB_RW - 1);
+                    rb = ptr - (RW - 1);
                     rb += (int32_t)((16u - (uint32_t)((uintptr_t)(rec + rb) >> 2)) & 15u);
                     const uint32_t *src = rec + rb;
 #pragma unroll
-                    for (int c = 0; c < TB_RW / 4; c++) {
+                    for (int c = 0; c < RW / 4; c++) {
                         const u32x4 v = *(const u32x4 *)(src + 4 * c);
                         uint32_t *w = rwin + (4 * c) * TB_LANES + lane;
                         w[0] = v.x; w[TB_LANES] = v.y; w[2 * TB_LANES] = v.z; w[3 * TB_LANES] = v.w;
@@ -2842,6 +2845,7 @@ struct gba_ctx {
     uint32_t affine_top_slots = 0;   // affine gaps: a third lane class of this many slots (env GBA_AFFINE_TOP_SLOTS; 0: none).  Measured on 98 304 pairs
                                      // of 20 kb, band 16 (99 % of them fit 96 slots): none 221 GCUPS, 96 slots 212, 80 slots 190, 128 slots 187: three
                                      // lane-per-pair waves per CU are no faster than the narrow wave-per-pair kernel
+    uint32_t tb_few_max = 32768;         // affine lane-per-pair tracebacks of at most this many pairs (two waves per CU) use the large record window (env GBA_TB_FEW_MAX)
     uint32_t tb_wave_max = 6144;         // a batch that ran on the wave kernels altogether with at most this many narrow-class pairs is walked
                                          // back one wave per pair too (measured crossover: 6 600 pairs of 10 kb, 10 600 of 20 kb affine; env GBA_TB_WAVE_MAX)
     uint32_t quad_affine_min = 10240;   // narrow affine wave class: this many pairs or more run four pairs per wave (fewer leave SIMDs
@@ -3033,7 +3037,8 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
     auto launch_tb_lanes = [&](hipStream_t st) {
         const uint32_t cnt = pl.cls_base[CLS_WIDE];
         const dim3 grid((cnt + TB_LANES - 1) / TB_LANES), block(TB_LANES);
-        if (aff) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, st, d, c->tbc, res, 0u, cnt);
+        if (aff && cnt <= c->tb_few_max) hipLaunchKernelGGL((k_traceback<true, TB_RW_FEW>), grid, block, 0, st, d, c->tbc, res, 0u, cnt);
+        else if (aff) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, st, d, c->tbc, res, 0u, cnt);
         else hipLaunchKernelGGL(k_traceback<false>, grid, block, 0, st, d, c->tbc, res, 0u, cnt);
     };
     HIPCHK(c, hipEventRecord(sl.ev_fork, s));
@@ -3625,6 +3630,7 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
         if (const char *e = getenv("GBA_PART_PAIRS")) c->part_pairs = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_WAVE_PAIRS")) c->wave_pairs = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_TB_WAVE_MAX")) c->tb_wave_max = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char *e = getenv("GBA_TB_FEW_MAX")) c->tb_few_max = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_QUAD_AFFINE_MIN")) c->quad_affine_min = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_WAVE_PAIRS_AFFINE")) c->wave_pairs_affine = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_AFFINE_TOP_SLOTS")) { const uint32_t v = (uint32_t)strtoul(e, nullptr, 10); if (v == 0 || (v > 64 && v <= 128)) c->affine_top_slots = v; }

@@ -25,13 +25,16 @@ def ctx(api, request):
     (the library itself sends batches too small to fill the GPU there; the narrow affine wave class four pairs per wave,
     which the library does for large batches only: the one-pair-per-wave instance is what tests/test_gpu_qv_guided.py, the
     randomised driver and every other test file's small affine batches run)."""
-    old = {k: os.environ.get(k) for k in ("GBA_WAVE_PAIRS", "GBA_WAVE_PAIRS_AFFINE", "GBA_QUAD_AFFINE_MIN", "GBA_TB_WAVE_MAX")}
+    old = {k: os.environ.get(k) for k in ("GBA_WAVE_PAIRS", "GBA_WAVE_PAIRS_AFFINE", "GBA_QUAD_AFFINE_MIN", "GBA_TB_WAVE_MAX", "GBA_TB_FEW_MAX")}
     v = "0" if request.param == "lane-per-pair" else "4000000000"
     os.environ["GBA_WAVE_PAIRS"] = os.environ["GBA_WAVE_PAIRS_AFFINE"] = v
     os.environ["GBA_QUAD_AFFINE_MIN"] = "0"
     # the narrow wave class walked back by the lane-per-pair traceback, as in large batches; small batches on a default
     # context (the other test files, the randomised driver) are walked back one wave per pair
     os.environ["GBA_TB_WAVE_MAX"] = "0"
+    # affine pairs walked back with the record window of full batches (small batches on a default context take the large
+    # one: test_affine_lane_traceback_windows_agree, the other test files, the randomised driver)
+    os.environ["GBA_TB_FEW_MAX"] = "0"
     c = api.Context(0, timing=True)
     for k, o in old.items():
         if o is None:
@@ -774,6 +777,32 @@ def test_small_batches_walk_back_one_wave_per_pair(api, oracle, synth, monkeypat
         c = api.Context(0, timing=True)
         pairs, blocks = _run(c, api, oracle, batch, **kw)
         assert int(c.timing()["wide_pairs"]) == 300
+        outs.append((pairs.tobytes(), blocks.tobytes()))
+        c.close()
+    assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("band", [16, 50])
+@pytest.mark.parametrize("wave_pairs", ["0", "4000000000"], ids=["lane-classes", "narrow-wave-class"])
+def test_affine_lane_traceback_windows_agree(api, oracle, synth, monkeypatch, band, wave_pairs):
+    """The lane-per-pair traceback of affine pairs keeps 64 record dwords per lane in its window, or 192 when the launch has
+    few pairs (rows of 33 cells are ten dwords; rows of 101 cells are 27 and leave the small window every other row): the
+    same bytes either way, and the oracle's results."""
+    from blasr_amd import _lib
+    batch = synth.compact_blocks(synth.generate(600, read_len=1500, len_jitter=1400, seed=23))
+    kw = dict(mode=_lib.MODE_AFFINE, band=band, affine_open=5, affine_extend=2, stats_affine=1)
+    monkeypatch.setenv("GBA_WAVE_PAIRS_AFFINE", wave_pairs)
+    monkeypatch.setenv("GBA_TB_WAVE_MAX", "0")            # the narrow wave class walked back one lane per pair too
+    outs = []
+    for few in ("0", None):
+        if few is None:
+            monkeypatch.delenv("GBA_TB_FEW_MAX", raising=False)
+        else:
+            monkeypatch.setenv("GBA_TB_FEW_MAX", few)
+        c = api.Context(0, timing=True)
+        pairs, blocks = _run(c, api, oracle, batch, **kw)
+        if wave_pairs != "0":
+            assert int(c.timing()["wide_pairs"]) == 600
         outs.append((pairs.tobytes(), blocks.tobytes()))
         c.close()
     assert outs[0] == outs[1]
