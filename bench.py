@@ -23,6 +23,7 @@ Beside the device-resident rate (`value`) the line carries, on rank 0 at N=1:
                 host memory (targets as windows of the resident reference)
   cpu_baseline  the CPU oracle on all host cores over a bounded sample of the batch
   other_workloads  BASELINE configs 3, 4 and 5 device-resident, two steps each; for the one-part batches (3, 5) also streamed through two contexts
+  streamed      the same batch streamed through two contexts by two threads (device-resident)
   end_to_end    reads in, filtered and scored alignments out (read-level harness)
 
 Prints ONE JSON line on rank 0.
@@ -341,6 +342,7 @@ def main():
     ap.add_argument("--no-fixed-band", action="store_true", help="skip the gba_kband (end extension) measurement")
     ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configurations (other_workloads)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the read-level harness (end_to_end)")
+    ap.add_argument("--no-streamed", action="store_true", help="skip the two-context streaming measurement (streamed)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N > 1: weak = --pairs per GPU (default), strong = --pairs in all, split over the GPUs")
     ap.add_argument("--cigar", type=int, default=None, help="also have the device write CIGAR operations (GBA_CIGAR_* flags); not part of the default line")
@@ -514,6 +516,41 @@ def main():
     }
     if cigar is not None:
         out["cigar"] = {"flags": args.cigar, "operations_per_step": ctx.cigar_needed}
+
+    if rank == 0 and world == 1 and not args.no_streamed and cigar is None:
+        # The same batches streamed: two contexts on the GPU, a thread each (the reference's worker threads with a
+        # MappingBuffers each, /root/reference/iblasr/Blasr.cpp:771), so that one batch's first packing and guide and its
+        # last traceback run under the other batch's fills.  After the timed region, not in `value`.
+        try:
+            import threading
+            ctx2 = api.Context(local)
+            ctx2.set_scoring(scoring)
+            out2 = (torch.zeros_like(out_pairs), torch.zeros_like(out_blocks))
+            rcs = [0, ctx2.refine_device(dbatch, *out2)[0]]              # (scratch allocation)
+            per_thread = max(args.steps, 4)
+
+            def stream(i, c, o):
+                for _ in range(per_thread):
+                    rcs[i] = rcs[i] or c.refine_device(dbatch, *o)[0]
+
+            th = [threading.Thread(target=stream, args=(0, ctx, (out_pairs, out_blocks))), threading.Thread(target=stream, args=(1, ctx2, out2))]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t1) / (2 * per_thread)
+            out["streamed"] = {"what": "the same batch streamed through two contexts by two threads, %d batches each" % per_thread,
+                               "contexts": 2, "rc": int(rcs[0] or rcs[1]), "ms_per_batch": round(dt2 * 1e3, 3),
+                               "gcups": round(cells_step / dt2 / 1e9, 2), "same_results": bool(torch.equal(out_pairs, out2[0])),
+                               "device_bytes": 2 * int(tm["device_bytes"])}
+            ctx2.close()
+            del out2, ctx2
+            torch.cuda.empty_cache()
+        except Exception as e:              # a failure here must not cost the headline line
+            out["streamed"] = {"error": repr(e)[:300]}
 
     if rank == 0 and world == 1 and not args.no_guides:
         # The step in front of the path, on the same batch: guides made on the device from the sequences

@@ -2,7 +2,7 @@
 # usage: run_others.sh name1 name2 ...   other_workloads of the bench line for experiment libraries ("base" = shipped)
 for n in "$@"; do
   if [ "$n" = base ]; then unset GBA_LIB; else export GBA_LIB=$PWD/exp_build/libgba_$n.so; fi
-  timeout -k 10 300 python3 bench.py --steps 1 --warmup 0 --no-cpu --no-host --no-guides --no-fixed-band --no-end-to-end > gpurun_out/o_$n.json 2>gpurun_out/o_$n.err || exit 1
+  timeout -k 10 300 python3 bench.py --steps 1 --warmup 0 --no-cpu --no-host --no-guides --no-fixed-band --no-end-to-end --no-streamed > gpurun_out/o_$n.json 2>gpurun_out/o_$n.err || exit 1
   python3 - "$n" <<'P'
 import json, sys
 d = json.loads(open("gpurun_out/o_%s.json" % sys.argv[1]).read().strip().splitlines()[-1])
