@@ -254,6 +254,25 @@ def kernel_name(cfg, tm, n, quad_min):
     return "k_fill<%s>" % ("true" if affine else "false")
 
 
+def stream_batches(torch, pipe, dbatch, bufs, warm, count):
+    """`count` runs of the batch through the pipeline's contexts in turn, as many in flight as it has contexts, after
+    `warm` untimed ones (scratch allocation).  Returns (seconds per batch, first non-zero return code or 0)."""
+    depth = len(pipe.ctxs)
+    rc = 0
+    for phase, total in ((0, warm), (1, count)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(total):
+            if k >= depth:
+                rc = rc or pipe.wait()[0]
+            pipe.submit(dbatch, *bufs[k % depth])
+        for _ in range(min(depth, total)):
+            rc = rc or pipe.wait()[0]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return dt / count, int(rc)
+
+
 def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None, two_contexts=False):
     """One of the other BASELINE configurations, device-resident like the headline: generate, one warm-up step, `steps`
     timed steps; the same definitions of GCUPS and of the fill's share of the int32 VALU peak.  two_contexts: also the
@@ -295,31 +314,15 @@ def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None,
          "fill_ms": round(fill_s * 1e3, 3), "traceback_ms": round(tb / steps, 3), "fill_gcups": round(cells / fill_s / 1e9, 2),
          "frac": round(cells * ops / fill_s / 1e12 / VALU_PEAK_TOPS, 4), "steps": steps}
     if two_contexts:
-        import threading
-        ctx2 = api.Context(0)
-        ctx2.set_scoring(api.make_scoring(band=cfg["band"], max_band=max_band, mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR))
-        out2 = (torch.zeros_like(out_pairs), torch.zeros_like(out_blocks))
-        rcs = [rc, ctx2.refine_device(d, *out2)[0]]
-        per_thread = max(steps, 5)
-
-        def stream(i, c, o):
-            for _ in range(per_thread):
-                rcs[i] = rcs[i] or c.refine_device(d, *o)[0]
-
-        th = [threading.Thread(target=stream, args=(0, ctx, (out_pairs, out_blocks))), threading.Thread(target=stream, args=(1, ctx2, out2))]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        torch.cuda.synchronize()
-        dt2 = (time.perf_counter() - t0) / (2 * per_thread)
-        r["two_contexts"] = {"what": "batches streamed through two contexts by two threads", "rc": int(rcs[0] or rcs[1]), "batches": 2 * per_thread,
-                             "ms_per_batch": round(dt2 * 1e3, 3), "gcups": round(cells / dt2 / 1e9, 2),
-                             "same_results": bool(torch.equal(out_pairs, out2[0]))}
-        ctx2.close()
-        del out2
+        pipe = api.DevicePipeline(0, depth=2, contexts=[ctx])
+        pipe.set_scoring(api.make_scoring(band=cfg["band"], max_band=max_band, mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR))
+        bufs = [(out_pairs, out_blocks), (torch.zeros_like(out_pairs), torch.zeros_like(out_blocks))]
+        dt2, rc2 = stream_batches(torch, pipe, d, bufs, 2, 2 * max(steps, 5))
+        r["two_contexts"] = {"what": "batches streamed through two contexts, a worker thread each (api.DevicePipeline)", "rc": rc2,
+                             "batches": 2 * max(steps, 5), "ms_per_batch": round(dt2 * 1e3, 3), "gcups": round(cells / dt2 / 1e9, 2),
+                             "same_results": bool(torch.equal(bufs[0][0], bufs[1][0]))}
+        pipe.close()
+        del bufs
     ctx.close()
     del d, out_pairs, out_blocks
     torch.cuda.empty_cache()
@@ -518,36 +521,21 @@ def main():
         out["cigar"] = {"flags": args.cigar, "operations_per_step": ctx.cigar_needed}
 
     if rank == 0 and world == 1 and not args.no_streamed and cigar is None:
-        # The same batches streamed: two contexts on the GPU, a thread each (the reference's worker threads with a
-        # MappingBuffers each, /root/reference/iblasr/Blasr.cpp:771), so that one batch's first packing and guide and its
+        # The same batches streamed: a second context on the GPU and a thread for each (the reference's worker threads with
+        # a MappingBuffers each, /root/reference/iblasr/Blasr.cpp:771), so that one batch's first packing and guide and its
         # last traceback run under the other batch's fills.  After the timed region, not in `value`.
         try:
-            import threading
-            ctx2 = api.Context(local)
-            ctx2.set_scoring(scoring)
-            out2 = (torch.zeros_like(out_pairs), torch.zeros_like(out_blocks))
-            rcs = [0, ctx2.refine_device(dbatch, *out2)[0]]              # (scratch allocation)
-            per_thread = max(args.steps, 4)
-
-            def stream(i, c, o):
-                for _ in range(per_thread):
-                    rcs[i] = rcs[i] or c.refine_device(dbatch, *o)[0]
-
-            th = [threading.Thread(target=stream, args=(0, ctx, (out_pairs, out_blocks))), threading.Thread(target=stream, args=(1, ctx2, out2))]
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t1) / (2 * per_thread)
-            out["streamed"] = {"what": "the same batch streamed through two contexts by two threads, %d batches each" % per_thread,
-                               "contexts": 2, "rc": int(rcs[0] or rcs[1]), "ms_per_batch": round(dt2 * 1e3, 3),
-                               "gcups": round(cells_step / dt2 / 1e9, 2), "same_results": bool(torch.equal(out_pairs, out2[0])),
+            pipe = api.DevicePipeline(local, depth=2, contexts=[ctx])
+            pipe.set_scoring(scoring)
+            bufs = [(out_pairs, out_blocks), (torch.zeros_like(out_pairs), torch.zeros_like(out_blocks))]
+            count = 2 * max(args.steps, 4)
+            dt2, rc2 = stream_batches(torch, pipe, dbatch, bufs, 2, count)
+            out["streamed"] = {"what": "the same batch streamed through two contexts, a worker thread each (api.DevicePipeline), %d batches" % count,
+                               "contexts": 2, "rc": rc2, "ms_per_batch": round(dt2 * 1e3, 3),
+                               "gcups": round(cells_step / dt2 / 1e9, 2), "same_results": bool(torch.equal(bufs[0][0], bufs[1][0])),
                                "device_bytes": 2 * int(tm["device_bytes"])}
-            ctx2.close()
-            del out2, ctx2
+            pipe.close()
+            del bufs, pipe
             torch.cuda.empty_cache()
         except Exception as e:              # a failure here must not cost the headline line
             out["streamed"] = {"error": repr(e)[:300]}

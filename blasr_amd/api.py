@@ -490,6 +490,61 @@ class HostPipeline:
         return c.wait_host()
 
 
+class DevicePipeline:
+    """HostPipeline's counterpart for batches that are already in device memory: several contexts on ONE GPU used in turn,
+    a worker thread each (gba_submit_device returns when its batch has completed), so that batch k+1 starts while batch k
+    runs: the first packing and guide of one batch and the last traceback of the other run under fills instead of alone,
+    and a batch of a single part (too few pairs to be cut) no longer has its traceback to itself.  Measured: 491 520
+    pairs of 10 kb 830 -> 890-903 GCUPS, 16 384 affine pairs of 20 kb 193 -> 256-262.  Every context holds its own scratch.
+    Set GPU_MAX_HW_QUEUES=16 in the environment before the HIP runtime starts."""
+
+    def __init__(self, device=0, depth=2, contexts=()):
+        """contexts: contexts of this GPU the caller already has (they keep their scoring, reference and scratch and stay
+        open when the pipeline is closed); the pipeline adds its own up to `depth`."""
+        from concurrent.futures import ThreadPoolExecutor
+        self._own = [Context(device) for _ in range(max(depth - len(contexts), 0))]
+        self.ctxs = list(contexts) + self._own
+        self._pools = [ThreadPoolExecutor(max_workers=1) for _ in self.ctxs]
+        self._futures = []            # batches in flight, oldest first
+        self._sub = 0
+
+    def close(self):
+        for f in self._futures:
+            f.exception()             # let what is in flight finish
+        self._futures = []
+        for p in self._pools:
+            p.shutdown(wait=True)
+        for c in self._own:
+            c.close()
+
+    def set_scoring(self, scoring):
+        for c in self.ctxs:
+            c.set_scoring(scoring)
+
+    def set_guide_producer(self, params):
+        for c in self.ctxs:
+            c.set_guide_producer(params)
+
+    def set_reference(self, ref):
+        for c in self.ctxs:
+            c.set_reference(ref)
+
+    def submit(self, dbatch, out_pairs, out_blocks, cigar=None):
+        """Queues a batch on the next context (arguments as Context.refine_device).  At most `depth` batches may be in
+        flight; their inputs and outputs must stay untouched until wait() has returned them."""
+        if len(self._futures) >= len(self.ctxs):
+            raise GbaError(_lib.E_STATE)
+        i = self._sub % len(self.ctxs)
+        self._futures.append(self._pools[i].submit(self.ctxs[i].refine_device, dbatch, out_pairs, out_blocks, False, cigar))
+        self._sub += 1
+
+    def wait(self):
+        """Waits for the oldest submitted batch.  Returns (rc, blocks_needed); raises what its call raised."""
+        if not self._futures:
+            raise GbaError(_lib.E_STATE)
+        return self._futures.pop(0).result()
+
+
 def to_device(batch, device="cuda:0"):
     """Copy a host batch dict to torch CUDA tensors (bit patterns preserved)."""
     import torch

@@ -80,3 +80,43 @@ def test_two_contexts_per_worker_overlap_batches(synth):
     finally:
         m.close()
         one.close()
+
+
+def test_device_pipeline_equals_one_context(synth):
+    """Device-resident batches streamed through two contexts on one GPU, a worker thread each (api.DevicePipeline): every
+    batch comes back with the bytes one context gives, in submission order, whatever overlaps with what."""
+    import torch
+    from blasr_amd import _lib, api
+    batches = [synth.compact_blocks(synth.generate(n, read_len=rl, len_jitter=rl // 2, seed=900 + i))
+               for i, (n, rl) in enumerate(((500, 1500), (64, 4000), (900, 700), (1, 300), (300, 2500)))]
+    dev = [api.to_device(b) for b in batches]
+    outs = [(torch.zeros(int(b["n_pairs"]) * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0"),
+             torch.zeros((int(b["q_len"].astype(np.int64).sum()) + int(b["n_pairs"]), 3), dtype=torch.int32, device="cuda:0")) for b in batches]
+    one = api.Context(0)
+    one.set_scoring(api.make_scoring())
+    want = []
+    for d, o in zip(dev, outs):
+        rc, needed = one.refine_device(d, *o)
+        assert rc == 0
+        want.append((o[0].cpu().numpy().tobytes(), o[1][:needed].cpu().numpy().tobytes(), needed))
+        o[0].zero_(); o[1].zero_()
+    one.close()
+    pipe = api.DevicePipeline(0, depth=2)
+    try:
+        pipe.set_scoring(api.make_scoring())
+        with pytest.raises(api.GbaError):
+            pipe.wait()                                   # nothing in flight
+        got = []
+        for k in range(len(dev)):
+            if k >= 2:
+                got.append(pipe.wait())
+            pipe.submit(dev[k], *outs[k])
+        with pytest.raises(api.GbaError):
+            pipe.submit(dev[0], *outs[0])                 # two in flight already
+        got.append(pipe.wait()); got.append(pipe.wait())
+        for k, (rc, needed) in enumerate(got):
+            assert rc == 0 and needed == want[k][2]
+            assert outs[k][0].cpu().numpy().tobytes() == want[k][0]
+            assert outs[k][1][:needed].cpu().numpy().tobytes() == want[k][1]
+    finally:
+        pipe.close()
