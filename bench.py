@@ -22,7 +22,7 @@ Beside the device-resident rate (`value`) the line carries, on rank 0 at N=1:
   host_to_host  the same batch through gba_submit / gba_wait from and to page-locked
                 host memory (targets as windows of the resident reference)
   cpu_baseline  the CPU oracle on all host cores over a bounded sample of the batch
-  other_workloads  BASELINE configs 3, 4 and 5 device-resident, two steps each; for the one-part batches (3, 5) also streamed through two contexts
+  other_workloads  BASELINE configs 3, 4 and 5 device-resident, two steps each; for the one-part batches (3, 5) also streamed through four contexts
   streamed      the same batch streamed through two contexts by two threads (device-resident)
   end_to_end    reads in, filtered and scored alignments out (read-level harness)
 
@@ -273,12 +273,12 @@ def stream_batches(torch, pipe, dbatch, bufs, warm, count):
     return dt / count, int(rc)
 
 
-def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None, two_contexts=False):
+def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None, stream_depth=0):
     """One of the other BASELINE configurations, device-resident like the headline: generate, one warm-up step, `steps`
-    timed steps; the same definitions of GCUPS and of the fill's share of the int32 VALU peak.  two_contexts: also the
-    rate of a caller that streams such batches through two contexts from two threads (the reference's worker threads, one
-    MappingBuffers each, /root/reference/iblasr/Blasr.cpp:771): a batch of this size is one part, whose traceback then
-    runs under the other context's fill."""
+    timed steps; the same definitions of GCUPS and of the fill's share of the int32 VALU peak.  stream_depth: also the
+    rate of a caller that streams such batches through that many contexts, a worker thread each (the reference's worker
+    threads, one MappingBuffers each, /root/reference/iblasr/Blasr.cpp:771): a batch of this size is one part, whose
+    traceback then runs under the other contexts' fills, and the wave-per-pair fills of several batches share the SIMDs."""
     cfg = dict(synth.PRESETS[name])
     if band is not None:
         cfg["band"] = band
@@ -313,14 +313,15 @@ def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None,
          "kernel": kernel_name(cfg, tm, n, int(os.environ.get("GBA_QUAD_AFFINE_MIN", "10240"))),
          "fill_ms": round(fill_s * 1e3, 3), "traceback_ms": round(tb / steps, 3), "fill_gcups": round(cells / fill_s / 1e9, 2),
          "frac": round(cells * ops / fill_s / 1e12 / VALU_PEAK_TOPS, 4), "steps": steps}
-    if two_contexts:
-        pipe = api.DevicePipeline(0, depth=2, contexts=[ctx])
+    if stream_depth > 1:
+        pipe = api.DevicePipeline(0, depth=stream_depth, contexts=[ctx])
         pipe.set_scoring(api.make_scoring(band=cfg["band"], max_band=max_band, mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR))
-        bufs = [(out_pairs, out_blocks), (torch.zeros_like(out_pairs), torch.zeros_like(out_blocks))]
-        dt2, rc2 = stream_batches(torch, pipe, d, bufs, 2, 2 * max(steps, 5))
-        r["two_contexts"] = {"what": "batches streamed through two contexts, a worker thread each (api.DevicePipeline)", "rc": rc2,
-                             "batches": 2 * max(steps, 5), "ms_per_batch": round(dt2 * 1e3, 3), "gcups": round(cells / dt2 / 1e9, 2),
-                             "same_results": bool(torch.equal(bufs[0][0], bufs[1][0]))}
+        bufs = [(out_pairs, out_blocks)] + [(torch.zeros_like(out_pairs), torch.zeros_like(out_blocks)) for _ in range(stream_depth - 1)]
+        count = stream_depth * max(steps, 4)
+        dt2, rc2 = stream_batches(torch, pipe, d, bufs, stream_depth, count)
+        r["streamed"] = {"what": "batches streamed through %d contexts, a worker thread each (api.DevicePipeline)" % stream_depth, "contexts": stream_depth,
+                         "rc": rc2, "batches": count, "ms_per_batch": round(dt2 * 1e3, 3), "gcups": round(cells / dt2 / 1e9, 2),
+                         "same_results": all(bool(torch.equal(bufs[0][0], b_[0])) for b_ in bufs[1:])}
         pipe.close()
         del bufs
     ctx.close()
@@ -646,7 +647,7 @@ def main():
             try:
                 # (C4 is two parts, which overlap inside one context already: 2 % from a second one, not measured here)
                 out["other_workloads"][key] = other_workload(torch, api, synth, _lib, name, pairs, 2, args.max_band, band,
-                                                             two_contexts=key != "c4_chr20_bestn10")
+                                                             stream_depth=0 if key == "c4_chr20_bestn10" else 4)
             except Exception as e:          # a failure here must not cost the headline line
                 out["other_workloads"][key] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_end_to_end and args.workload == "c2_10kb_linear":

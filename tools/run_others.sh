@@ -6,6 +6,6 @@ for n in "$@"; do
   python3 - "$n" <<'P'
 import json, sys
 d = json.loads(open("gpurun_out/o_%s.json" % sys.argv[1]).read().strip().splitlines()[-1])
-print(sys.argv[1], d["value"], {k: (v["gcups"], v["ms_per_step"], v["fill_ms"], v["traceback_ms"]) for k, v in d["other_workloads"].items()})
+print(sys.argv[1], d["value"], {k: (v["gcups"], v["ms_per_step"], v["fill_ms"], v["traceback_ms"], (v.get("streamed") or {}).get("gcups")) for k, v in d["other_workloads"].items()})
 P
 done
