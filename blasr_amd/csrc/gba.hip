@@ -2832,6 +2832,7 @@ struct gba_ctx {
     // slots of the part pipeline a batch uses (each holds the scratch of one part): batches whose buffers are on the
     // device (env GBA_SLOTS_DEVICE) and host-buffer batches (env GBA_SLOTS_HOST); 2 .. NSLOT
     uint32_t slots_device = NSLOT, slots_host = 2;
+    bool fill_chain = false;         // a part's fill launches wait for the end of the bulk fill of the part before (env GBA_FILL_CHAIN)
     uint32_t scratch_retries = 0;    // batches repeated with full-size block scratch
     uint32_t sdp_queue = 1024;       // hits queued per tile (env GBA_SDP_QUEUE, 64..16384)
     uint32_t sdp_tile_max = 2048;
@@ -3013,7 +3014,7 @@ int phase_guide(gba_ctx *c, Slot &sl, Dev &d)
 // the traceback does not care about the class); the wave-per-pair class has its own traceback
 // behind its fill.  An auxiliary stream therefore carries fills only, and the next part's wide
 // class, which shares a hardware queue with this one's, does not wait behind a traceback.
-int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_aux)
+int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_aux, hipEvent_t after = nullptr)
 {
     const gba_scoring &sc = c->sc;
     HIPCHK(c, hipStreamSynchronize(sl.s));
@@ -3023,6 +3024,7 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
     d.rec = (uint32_t *)((uint8_t *)sl.b_rec.ptr + ARENA_SLACK);
     hipStream_t s = sl.s;
     hipLaunchKernelGGL(k_results_init, dim3((d.n + 255) / 256), dim3(256), 0, s, d, res);
+    if (after) HIPCHK(c, hipStreamWaitEvent(s, after, 0));
     HIPCHK(c, hipEventRecord(sl.t_fill0, s));
     const bool aff = sc.mode == GBA_MODE_AFFINE;
     const bool local = sc.align_type == GBA_ALIGN_LOCAL;    // linear gaps only (gba_set_scoring)
@@ -3385,7 +3387,7 @@ int run_device_once(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io
         if (timing && used[h % ns]) { rc = fold_timing(c, sl, acc); if (rc) return rc; }
         used[h % ns] = true;
         rc = phase_guide(c, sl, d); if (rc) return rc;
-        rc = phase_fill(c, sl, d, res + first, (uint32_t)NAUXS); if (rc) return rc;
+        rc = phase_fill(c, sl, d, res + first, (uint32_t)NAUXS, c->fill_chain && h > 0 ? c->slot[(h - 1) % ns].t_fill1 : nullptr); if (rc) return rc;
         if (io && !io->all_ahead && h + 1 < parts) {       // the next part's inputs travel while this part runs
             const uint32_t nf = (h + 1) * per;
             rc = stage_part(c, *io, nf, n - nf < per ? n - nf : per, c->ev_in[h + 1]); if (rc) return rc;
@@ -3639,6 +3641,7 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
             if (v >= 256 && v <= 16384 && (v & (v - 1)) == 0) c->sdp_tile_max = v;
         }
         if (const char *e = getenv("GBA_SLOTS_DEVICE")) { const int v = atoi(e); if (v >= 2 && v <= NSLOT) c->slots_device = (uint32_t)v; }
+        if (const char *e = getenv("GBA_FILL_CHAIN")) c->fill_chain = atoi(e) != 0;
         if (const char *e = getenv("GBA_SLOTS_HOST")) { const int v = atoi(e); if (v >= 2 && v <= NSLOT) c->slots_host = (uint32_t)v; }
         if (const char *e = getenv("GBA_BLK_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 1024) c->blk_div = (uint32_t)v; }
         if (const char *e = getenv("GBA_BLK_POOL_DIV")) { const int v = atoi(e); if (v >= 1 && v <= (1 << 20)) c->blk_pool_div = (uint32_t)v; }
