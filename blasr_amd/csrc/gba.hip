@@ -273,6 +273,8 @@ __global__ void k_meta(Dev d, int mode, int kband_k, uint32_t score_a, uint32_t 
     }
     if (st == GBA_PAIR_OK && (Q > (mode == GBA_MODE_AFFINE ? MAX_ROWS_AFFINE : MAX_ROWS) || T > MAX_COLS)) st = GBA_PAIR_TOO_LONG;
     if (st == GBA_PAIR_OK && (uint64_t)Q * (128u + score_a) + (uint64_t)T * score_b >= score_lim) st = GBA_PAIR_TOO_LONG;
+    // the lane-per-pair fill of a batch with a cost profile puts the bias on the columns instead of the rows
+    if (st == GBA_PAIR_OK && d.prof && mode != GBA_MODE_AFFINE && (uint64_t)Q * score_a + (uint64_t)T * (128u + score_b) >= score_lim) st = GBA_PAIR_TOO_LONG;
     d.status[p] = st; d.qS[p] = qS; d.tS[p] = tS; d.Q[p] = Q; d.T[p] = T;
     d.rows[p] = st == GBA_PAIR_OK ? Q + 1 : 0;
     d.cols[p] = st == GBA_PAIR_OK ? T + 1 : 0;
@@ -763,9 +765,25 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // live in LDS (two rings), the deletion-gap state D travels along the row in a register.  Words
 // are score << 6 | arrow << 3 | low bits; the gap states put their own open/extend bit in bit 2
 // (I) and bit 1 (D).  Records hold one byte per cell: M arrow (bits 3..5), I bit, D bit.
-template <bool AFF>
+//
+// Quality-value variant (QV, linear gaps): the costs of a row come from the cost profile of its query base (Dev.prof:
+// five substitution costs, the insertion cost, five deletion costs, each taken within +-127), fetched by the lane one
+// row ahead, when it takes the row before, and turned into two byte tables for v_perm_b32 (substitution and deletion
+// by target code) and one addend (insertion) when the row is taken.  A table byte cannot be negative, so the deletion
+// costs carry a bias of 128 like the substitution costs: the bias of a cell is 128 x its COLUMN here (a diagonal move and
+// a move along the row add it, a move to the next row does not), where the matrix scorer's words carry 128 x the row.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t qv_bytes(uint32_t two)       // two int16 costs -> each within +-127, plus 128
+{
+    s16x2 x = __builtin_bit_cast(s16x2, two);
+    x = __builtin_elementwise_min(__builtin_elementwise_max(x, (s16x2)(short)-127), (s16x2)(short)127) + (s16x2)(short)128;
+    return __builtin_bit_cast(uint32_t, x);
+}
+
+template <bool AFF, bool QV = false>
 __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, uint32_t slots)
 {
+    static_assert(!(AFF && QV), "the affine quality-value DP runs one wave per pair");
     extern __shared__ uint32_t smem[];
     // Claims 200 of a SIMD's 512 VGPRs per wave, so that at most two fill waves (of any class) share
     // a SIMD and a wave of another kernel still fits beside them.  LDS would admit a third fill wave
@@ -808,6 +826,20 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) max_steps = max(max_steps, (uint32_t)__shfl_xor((int)max_steps, o, 64));
 
+    // QV: the profile of the pair's first DP row with a query base (row 1), the constants of row 0 (deletions in front of
+    // the first base cost fc.del), the arrow codes without a cost
+    const char *prow = QV ? (const char *)(d.prof + (d.q_off[p] + d.qS[p]) * 11) : nullptr;     // row r >= 1: 22 bytes at prow + 22 (r - 1)
+    uint32_t pa = 0, pb = 0, pc = 0, pd = 0, pe = 0, pf = 0;
+    if constexpr (QV) {
+        if (Q >= 1u) {
+            pa = *(const u32u1 *)(prow); pb = *(const u32u1 *)(prow + 4); pc = *(const u32u1 *)(prow + 8);
+            pd = *(const u32u1 *)(prow + 12); pe = *(const u32u1 *)(prow + 16); pf = *(const uint16_t *)(prow + 20);
+        }
+    }
+    const uint32_t del0 = (uint32_t)(fc.del + 128) & 255u;
+    const int32_t codeU8 = fc.cU - ((fc.ins + 128) << 5), codeL8 = fc.cL - (fc.del << 5);
+    uint32_t dlo = 0, dhi = 0, ndlo = 0, ndhi = 0;      // deletion costs + 128 by target code, as mlo / mhi hold the substitution costs; the next row's
+    int32_t cUq = 0, ncUq = 0;                          // insertion cost << 5 | arrow code
     uint32_t rows_left = live ? Q + 1 : 0;              // rows not yet started
     uint32_t W = 0, dsh = 0, k0 = 0, Wp = 0;            // current row: width, shift, cells done; previous width
     uint32_t ext_left = 0, newslot = 0;
@@ -815,7 +847,8 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     bool first = true, finished = !live;
     uint32_t final_word = INFW;
     // the matrix row of the next word's query base is fetched one step ahead
-    uint32_t nmlo = tab[((R0.x >> 10) & 7u) * 2], nmhi = tab[((R0.x >> 10) & 7u) * 2 + 1];
+    uint32_t nmlo = 0, nmhi = 0;
+    if constexpr (!QV) { nmlo = tab[((R0.x >> 10) & 7u) * 2]; nmhi = tab[((R0.x >> 10) & 7u) * 2 + 1]; }
 
     // One step: `word` is this step's word of the stream, `next` the one after it.
     auto step = [&](const uint32_t word, const uint32_t next) __attribute__((always_inline)) {
@@ -826,7 +859,16 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                 rows_left--;
                 Wp = W;
                 W = word & ROW_W_MASK; dsh = (word >> 13) & 1023u;
-                mlo = nmlo; mhi = nmhi;
+                if constexpr (QV) {
+                    const uint32_t r = Q - rows_left;           // the row taken now
+                    mlo = nmlo; mhi = nmhi; dlo = ndlo; dhi = ndhi; cUq = ncUq;
+                    if (r == 0u) { dlo = del0 * 0x01010100u; dhi = del0 * 0x01010101u; }     // (row 1's costs stay where they are)
+                    else if (r < Q) {                           // row r + 1 takes the costs of query base r
+                        const char *nx = prow + 22u * r;
+                        pa = *(const u32u1 *)(nx); pb = *(const u32u1 *)(nx + 4); pc = *(const u32u1 *)(nx + 8);
+                        pd = *(const u32u1 *)(nx + 12); pe = *(const u32u1 *)(nx + 16); pf = *(const uint16_t *)(nx + 20);
+                    }
+                } else { mlo = nmlo; mhi = nmhi; }
                 const uint32_t tot = dsh + W;
                 const uint32_t nnew = tot > Wp ? tot - Wp : 0u;
                 uint32_t *ns = lds + Wp * 64 + lane;
@@ -869,7 +911,7 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                     if (first) {
                         // row 0: linear starts from "one deletion before column 0" so that cell j costs j
                         // deletions; affine makes the diagonal candidate of cell (0,0) cost exactly 0
-                        if constexpr (AFF) diag = (uint32_t)fc.diag0; else left = (uint32_t)(-fc.del * 32);
+                        if constexpr (AFF) diag = (uint32_t)fc.diag0; else left = (uint32_t)(-(fc.del + (QV ? 128 : 0)) * 32);
                     }
                     first = false;
                 }
@@ -893,8 +935,10 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                             const uint32_t tcd = u_ & 7u;
                             const uint32_t sb = __builtin_amdgcn_perm(mhi, mlo, tcd);   // selector bytes 1..3 = 0 read the zero byte
                             const int32_t m = (int32_t)((sb << SH) + diag);
-                            const int32_t u = (int32_t)u_ + fc.cU;
-                            const int32_t l = (int32_t)left + fc.cL;
+                            const int32_t u = (int32_t)u_ + (QV ? cUq : fc.cU);
+                            int32_t l;
+                            if constexpr (QV) l = (int32_t)((__builtin_amdgcn_perm(dhi, dlo, tcd) << SH) + left) + codeL8;
+                            else l = (int32_t)left + fc.cL;
                             if constexpr (!AFF) {
                                 const uint32_t best = (uint32_t)min(m, min(u, l));
                                 const uint32_t cw = (u_ & TAGS) | (best & ~TAGS);
@@ -928,7 +972,17 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                     }
                 }
             }
-            nmlo = tab[((next >> 10) & 7u) * 2]; nmhi = tab[((next >> 10) & 7u) * 2 + 1];
+            if constexpr (!QV) { nmlo = tab[((next >> 10) & 7u) * 2]; nmhi = tab[((next >> 10) & 7u) * 2 + 1]; }
+            else {
+                // The tables of the lane's next row from what it fetched when it took the current one -- here, by every lane
+                // in every step (a lane that took no row this step gets what it had), and not where the next row is taken:
+                // a use there would wait for this step's record store as well, which is younger than the fetch.
+                const uint32_t a = qv_bytes(pa), b = qv_bytes(pb), c = qv_bytes(pc), e = qv_bytes(pd), f = qv_bytes(pe), g = qv_bytes(pf);
+                // byte 0 of the low word stays zero (the lookup's unused selector bytes read it); codes 5..7 read N's cost
+                nmlo = __builtin_amdgcn_perm(b, a, 0x0402000cu); nmhi = __builtin_amdgcn_perm(c, b, 0x04040402u);
+                ndlo = __builtin_amdgcn_perm(f, e, 0x0402000cu); ndhi = __builtin_amdgcn_perm(g, f, 0x04040402u);
+                ncUq = (int32_t)((c >> 16) << 5) + (codeU8 - 4096);
+            }
             if (did) {
                 // record: the arrow dwords of this step (stored whole; the tail past the row end is
                 // overwritten by what follows), then the row's meta dword once the row is done
@@ -975,7 +1029,7 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
         }
     }
     if (live) {
-        const int32_t v = (int32_t)(final_word & ~TAGS) - (int32_t)Q * (128 << SH);
+        const int32_t v = (int32_t)(final_word & ~TAGS) - (int32_t)(QV ? d.T[p] : Q) * (128 << SH);
         if (v >= UNREACH || !finished) d.status[p] = GBA_PAIR_UNREACHABLE;
         d.dp_score[p] = v >> SH;
     }
@@ -2931,10 +2985,12 @@ int launch_fill(gba_ctx *c, const Dev &d, uint32_t cls, uint32_t count, hipStrea
     if (!c->lds_attr_set) {                     // per device, and a ctx lives on one device
         HIPCHK(c, hipFuncSetAttribute((const void *)k_fill<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_fill<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(c, hipFuncSetAttribute((const void *)(k_fill<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         c->lds_attr_set = true;
     }
     const dim3 grid((count + 63) / 64), block(64);
     if (aff) hipLaunchKernelGGL(k_fill<true>, grid, block, lds, st, d, c->fc, cls, slots);
+    else if (d.prof) hipLaunchKernelGGL((k_fill<false, true>), grid, block, lds, st, d, c->fc, cls, slots);
     else hipLaunchKernelGGL(k_fill<false>, grid, block, lds, st, d, c->fc, cls, slots);
     HIPCHK(c, hipGetLastError());
     return GBA_OK;
@@ -2999,7 +3055,7 @@ int phase_guide(gba_ctx *c, Slot &sl, Dev &d)
     // pairs the whole batch runs one wave per pair.
     const bool affine = sc.mode == GBA_MODE_AFFINE;
     const bool local = sc.align_type == GBA_ALIGN_LOCAL;      // the free-start / best-cell end rule lives in the wave-per-pair kernels
-    const int lane_classes = local || d.prof || d.n < (affine ? c->wave_pairs_affine : c->wave_pairs) ? 0      // quality-value costs: the wave-per-pair kernels have them
+    const int lane_classes = local || (d.prof && affine) || d.n < (affine ? c->wave_pairs_affine : c->wave_pairs) ? 0      // affine gaps with quality-value costs: the wave-per-pair kernels have them
                            : affine ? (c->affine_top_slots ? LANE_CLS_AFFINE + 1 : LANE_CLS_AFFINE) : LANE_CLS_LINEAR;
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(SCAN_T), 0, sl.s, d, lane_classes, 1, affine ? c->affine_top_slots : 128u);
     HIPCHK(c, hipGetLastError());

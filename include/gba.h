@@ -47,7 +47,8 @@ enum {
     GBA_PAIR_TOO_LONG = 7,         /* more DP rows or columns than the kernels support (65535 rows, affine 32767; 2^20 columns),
                                       or rows x (128 + largest |substitution, insertion cost|) + columns x |deletion cost|
                                       reaches 2^24 (affine 2^23): the scores would not fit the kernels' cell words (a batch
-                                      with a q_profile is bounded with 127, affine 63, in place of the largest matrix / gap cost);
+                                      with a q_profile is bounded with 127, affine 63, in place of the largest matrix / gap cost,
+                                      and with linear gaps also by rows x 127 + columns x (128 + 127) below 2^24);
                                       gba_sdp_device: a read or window of more than 65535 bases */
     GBA_PAIR_TOO_MANY = 8,         /* gba_sdp_device only: more maximal matches than max_fragments, or more than
                                       64 x max_fragments k-mer hits (a repeat): no guide is produced */

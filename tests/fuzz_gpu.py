@@ -316,12 +316,17 @@ def main():
     from blasr_amd import api, synth, _lib, emit
     from oracle import oracle
     rng = np.random.default_rng(args.seed)
-    # two contexts used in turn: the library's defaults, and one whose narrow affine wave class always runs four pairs per
+    # three contexts used in turn: the library's defaults, one whose narrow affine wave class always runs four pairs per
     # wave (by default only batches of 10 240 pairs or more do, which these rounds never reach)
     os.environ["GBA_QUAD_AFFINE_MIN"] = "0"
     ctx_quad = api.Context(0)
     del os.environ["GBA_QUAD_AFFINE_MIN"]
-    ctxs = (api.Context(0), ctx_quad)
+    # and one that runs every batch on the lane-per-pair kernels as far as its pairs fit their classes (by default only
+    # batches of 20 480 pairs or more do, affine 57 344)
+    os.environ["GBA_WAVE_PAIRS"] = os.environ["GBA_WAVE_PAIRS_AFFINE"] = "1"
+    ctx_lanes = api.Context(0)
+    del os.environ["GBA_WAVE_PAIRS"], os.environ["GBA_WAVE_PAIRS_AFFINE"]
+    ctxs = (api.Context(0), ctx_quad, ctx_lanes)
     pool = ThreadPoolExecutor(16)
     t_end = time.time() + args.seconds
     rounds = pairs_done = fails = unsupported = cigar_rounds = sdp_rounds = kband_rounds = qv_rounds = packed_rounds = local_rounds = 0
@@ -329,7 +334,7 @@ def main():
     modes = {}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     while time.time() < t_end:
-        ctx = ctxs[(rounds >> 1) & 1]
+        ctx = ctxs[(rounds >> 1) % 3]
         kw = random_scoring(rng, _lib)
         batch = random_adversarial(rng, util) if rng.random() < 0.35 else random_synth(rng, synth)
         n = int(batch["n_pairs"])

@@ -43,21 +43,27 @@ def _check(oracle, batch, prof, OP, pairs, blocks):
         assert (kb == wb).all(), p
 
 
+@pytest.mark.parametrize("family", ["lane-per-pair", "wave-per-pair"])
 @pytest.mark.parametrize("band", [10, 120])
 @pytest.mark.parametrize("tie", [0, 1])
-def test_profile_costs_in_the_guided_dp(oracle, synth, band, tie):
+def test_profile_costs_in_the_guided_dp(oracle, synth, monkeypatch, band, tie, family):
+    """Both kernel families: one lane per pair (k_fill<false, true>; with band 120 only the pairs narrow enough for a
+    lane class) and one wave per pair (k_fill_wide<.., true>)."""
     import torch
     from blasr_amd import api, _lib
     rng = np.random.default_rng(5 + band + tie)
     batch = synth.compact_blocks(synth.generate(160, read_len=900, len_jitter=500, seed=31 + band))
     prof = _profile(rng, batch)
     kw = dict(band=band, tie_break=tie, ins=5, dele=4)
-    ctx = api.Context(0)
+    monkeypatch.setenv("GBA_WAVE_PAIRS", "1" if family == "lane-per-pair" else "4000000000")
+    ctx = api.Context(0, timing=True)
     ctx.set_scoring(api.make_scoring(**kw))
     OP = oracle.make_params(**kw)
     with_prof = dict(batch, q_profile=prof)
     pairs, blocks, rc = ctx.refine_host(with_prof)
     assert rc == 0 and int((pairs["status"] == 0).sum()) == 160
+    wide = int(ctx.timing()["wide_pairs"])
+    assert wide == 160 if family == "wave-per-pair" or band == 120 else wide == 0, wide
     _check(oracle, batch, prof, OP, pairs, blocks)
     # the costs matter: the same batch without them scores differently
     plain, _, _ = ctx.refine_host(batch)
@@ -76,12 +82,14 @@ def test_profile_costs_in_the_guided_dp(oracle, synth, band, tie):
     ctx.close()
 
 
-def test_profile_with_the_kband_geometry(oracle, synth):
+@pytest.mark.parametrize("k,family", [(150, "wave-per-pair"), (40, "lane-per-pair")])
+def test_profile_with_the_kband_geometry(oracle, synth, monkeypatch, k, family):
     from blasr_amd import api, _lib
     rng = np.random.default_rng(2)
-    batch = synth.compact_blocks(synth.generate(40, read_len=500, len_jitter=100, seed=9))
+    batch = synth.compact_blocks(synth.generate(40, read_len=500, len_jitter=100 if k == 150 else 30, seed=9))
     prof = _profile(rng, batch)
-    kw = dict(mode=_lib.MODE_KBAND, kband_k=150, ins=6, dele=6)
+    kw = dict(mode=_lib.MODE_KBAND, kband_k=k, ins=6, dele=6)
+    monkeypatch.setenv("GBA_WAVE_PAIRS", "1" if family == "lane-per-pair" else "4000000000")
     ctx = api.Context(0)
     ctx.set_scoring(api.make_scoring(**kw))
     pairs, blocks, rc = ctx.refine_host(dict(batch, q_profile=prof))
@@ -222,8 +230,9 @@ def test_cpp_shim_with_quality_values(oracle, synth):
 
 def test_a_profile_that_spells_out_the_matrix_gives_the_plain_results(synth, monkeypatch):
     """Size-independent property at the benchmark's read length: a profile whose costs are the matrix row of each
-    base, ins and del reproduces, on the wave-per-pair kernels with the prefix-sum deletion chain, exactly what the
-    lane-per-pair kernels give for the matrix scorer (8 192 pairs of 10 kb, no oracle involved)."""
+    base, ins and del reproduces, on the lane-per-pair kernel with per-row cost tables and on the wave-per-pair kernels
+    with the prefix-sum deletion chain, exactly what the lane-per-pair kernels give for the matrix scorer (8 192 pairs
+    of 10 kb, no oracle involved)."""
     import torch
     from blasr_amd import api, _lib
     n = 8192
@@ -239,27 +248,30 @@ def test_a_profile_that_spells_out_the_matrix_gives_the_plain_results(synth, mon
     prof[:, :5] = sub[qc]
     prof[:, 5] = kw["ins"]
     prof[:, 6:] = kw["dele"]
-    monkeypatch.setenv("GBA_WAVE_PAIRS", "1000")          # the plain run one lane per pair even at this batch size
-    ctx = api.Context(0, timing=True)
-    ctx.set_scoring(sc)
     d = api.to_device(host)
+    dp = dict(d, q_profile=torch.from_numpy(prof.reshape(-1)).to("cuda:0"))
     cap = int(host["q_len"].astype(np.int64).sum() // 4) + n
     outs = []
-    for b in (d, dict(d, q_profile=torch.from_numpy(prof.reshape(-1)).to("cuda:0"))):
+    # lane classes even at this batch size: the plain batch, the batch with the profile; then the latter one wave per pair
+    for wave_pairs, b in (("1000", d), ("1000", dp), ("4000000000", dp)):
+        monkeypatch.setenv("GBA_WAVE_PAIRS", wave_pairs)
+        ctx = api.Context(0, timing=True)
+        ctx.set_scoring(sc)
         op = torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0")
         ob = torch.zeros((cap, 3), dtype=torch.int32, device="cuda:0")
         rc, needed = ctx.refine_device(b, op, ob)
         torch.cuda.synchronize()
         assert rc == 0
         outs.append((op.cpu().numpy().tobytes(), ob[:needed].cpu().numpy().tobytes(), int(ctx.timing()["wide_pairs"])))
-    assert outs[0][:2] == outs[1][:2]
-    assert outs[0][2] < n // 2 and outs[1][2] == n           # lane-per-pair kernels against wave-per-pair kernels
-    ctx.close()
+        ctx.close()
+    assert outs[0][:2] == outs[1][:2] == outs[2][:2]
+    assert outs[0][2] < n // 2 and outs[1][2] == outs[0][2] and outs[2][2] == n
 
 
 def test_score_range_guard_counts_the_profile_costs(oracle, synth):
     """A pair near the row limit whose profile holds the largest costs the kernels take: its scores would leave the
-    cell word (rows x (128 + 127) + columns x 127 reaches 2^24), so it comes back TOO_LONG instead of a wrapped score;
+    cell word (rows x (128 + 127) + columns x 127, or rows x 127 + columns x (128 + 127), reaches 2^24), so it comes back
+    TOO_LONG instead of a wrapped score;
     a shorter one with the same costs fits and agrees with the oracle."""
     from blasr_amd import api, _lib
     ctx = api.Context(0)
