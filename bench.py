@@ -244,9 +244,13 @@ def launch_ranks(n_gpus):
     return subprocess.call(cmd)
 
 
-def kernel_name(cfg, tm, n, quad_min):
+def kernel_name(cfg, tm, n, quad_min, qv=False):
     """The fill kernel that ran the bulk of a batch, from the library's own routing."""
     affine = cfg["mode"] == "affine"
+    if qv:
+        if tm["wide_pairs"] * 2 > n:
+            return "k_fill_wide_affine<.., true>" if affine else "k_fill_wide<.., true>"
+        return "k_fill<false, true>"
     if tm["wide_pairs"] * 2 > n:               # most pairs ran wave-per-pair
         if affine:
             return "k_fill_quad_affine" if tm["wide_pairs"] >= quad_min and cfg["band"] <= 30 else "k_fill_wide_affine"
@@ -273,12 +277,15 @@ def stream_batches(torch, pipe, dbatch, bufs, warm, count):
     return dt / count, int(rc)
 
 
-def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None, stream_depth=0):
+def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None, stream_depth=0, qv=False):
     """One of the other BASELINE configurations, device-resident like the headline: generate, one warm-up step, `steps`
     timed steps; the same definitions of GCUPS and of the fill's share of the int32 VALU peak.  stream_depth: also the
     rate of a caller that streams such batches through that many contexts, a worker thread each (the reference's worker
     threads, one MappingBuffers each, /root/reference/iblasr/Blasr.cpp:771): a batch of this size is one part, whose
-    traceback then runs under the other contexts' fills, and the wave-per-pair fills of several batches share the SIMDs."""
+    traceback then runs under the other contexts' fills, and the wave-per-pair fills of several batches share the SIMDs.
+    qv: the batch carries a cost profile (gba_batch.q_profile, the quality-value scorers of
+    /root/reference/iblasr/BlasrUtilsImpl.hpp:636-646): random costs made on the device, 11 per base (match -5, the rest
+    1..29), so that every row of the DP looks its costs up in its own tables."""
     cfg = dict(synth.PRESETS[name])
     if band is not None:
         cfg["band"] = band
@@ -289,6 +296,17 @@ def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None,
     host = synth.generate(n, share_reads=k > 1, ref=ref, **{a: b for a, b in cfg.items() if a != "ref"})
     d = api.to_device(host, "cuda:0")
     cap = int(host["q_len"].astype(np.int64).sum() // 4) + n
+    if qv:
+        na = len(host["q_arena"])
+        code = np.full(256, 4, np.int64)
+        for i, c in enumerate(b"ACGT"):
+            code[c] = i
+        g = torch.Generator(device="cuda:0")
+        g.manual_seed(1)
+        prof = torch.randint(1, 30, (na, 11), dtype=torch.int16, device="cuda:0", generator=g)
+        prof[torch.arange(na, device="cuda:0"), torch.from_numpy(code[host["q_arena"]]).to("cuda:0")] = -5
+        d["q_profile"] = prof.reshape(-1)
+        del prof
     del host
     out_pairs = torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0")
     out_blocks = torch.zeros((cap, 3), dtype=torch.int32, device="cuda:0")
@@ -310,7 +328,7 @@ def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None,
     ops = OPS_PER_CELL[cfg["mode"]]
     r = {"pairs": n, "read_len": cfg["read_len"], "band": cfg["band"], "gaps": cfg["mode"], "candidates_per_read": k, "rc": rc,
          "pairs_ok": int((res["status"] == 0).sum()), "ms_per_step": round(dt * 1e3, 3), "gcups": round(cells / dt / 1e9, 2),
-         "kernel": kernel_name(cfg, tm, n, int(os.environ.get("GBA_QUAD_AFFINE_MIN", "10240"))),
+         "kernel": kernel_name(cfg, tm, n, int(os.environ.get("GBA_QUAD_AFFINE_MIN", "10240")), qv),
          "fill_ms": round(fill_s * 1e3, 3), "traceback_ms": round(tb / steps, 3), "fill_gcups": round(cells / fill_s / 1e9, 2),
          "frac": round(cells * ops / fill_s / 1e12 / VALU_PEAK_TOPS, 4), "steps": steps}
     if stream_depth > 1:
@@ -643,11 +661,13 @@ def main():
         # the other BASELINE configurations, device-resident, at the sizes the measurement plan names for them
         out["other_workloads"] = {}
         for key, name, pairs, band in (("c3_20kb_affine", "c3_20kb_affine", 16384, None), ("c5_50kb_band100", "c5_50kb_wide", 2048, 100),
-                                       ("c4_chr20_bestn10", "c4_chr20_bestn10", 163840, None)):
+                                       ("c4_chr20_bestn10", "c4_chr20_bestn10", 163840, None),
+                                       ("c2_10kb_quality_values", "c2_10kb_linear", 122880, None)):
             try:
                 # (C4 is two parts, which overlap inside one context already: 2 % from a second one, not measured here)
                 out["other_workloads"][key] = other_workload(torch, api, synth, _lib, name, pairs, 2, args.max_band, band,
-                                                             stream_depth=0 if key == "c4_chr20_bestn10" else 4)
+                                                             stream_depth=4 if key in ("c3_20kb_affine", "c5_50kb_band100") else 0,
+                                                             qv=key == "c2_10kb_quality_values")
             except Exception as e:          # a failure here must not cost the headline line
                 out["other_workloads"][key] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_end_to_end and args.workload == "c2_10kb_linear":
