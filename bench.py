@@ -319,7 +319,7 @@ def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None,
     for _ in range(steps):
         rc, _ = ctx.refine_device(d, out_pairs, out_blocks)
         tm = ctx.timing()
-        fill += tm["fill_ms"]; tb += tm["traceback_ms"]
+        fill += tm["fill_busy_ms"]; tb += tm["traceback_ms"]
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     res = out_pairs.cpu().numpy().view(_lib.PAIR_RESULT_DT)
@@ -427,15 +427,19 @@ def main():
 
     needed_dev = [0]
 
+    fill_sum = [0.0]
+
     def run_steps(count):
         fill = tb = 0.0
+        fill_sum[0] = 0.0
         for _ in range(count):
             rc, needed = ctx.refine_device(dbatch, out_pairs, out_blocks, cigar=cigar)   # returns when the batch has completed
             if rc != 0:
                 raise RuntimeError("refine_device rc=%d needed=%d" % (rc, needed))
             needed_dev[0] = needed
             tm = ctx.timing()
-            fill += tm["fill_ms"]; tb += tm["traceback_ms"]
+            fill += tm["fill_busy_ms"]; tb += tm["traceback_ms"]
+            fill_sum[0] += tm["fill_ms"]
         return fill, tb
 
     def barrier():
@@ -523,7 +527,10 @@ def main():
             "bound": "valu-int32", "kernel": kernel,
             "achieved": round(cells_step * ops_cell / fill_s / 1e12, 3), "peak": VALU_PEAK_TOPS,
             "unit": "Tops/s", "frac": round(cells_step * ops_cell / fill_s / 1e12 / VALU_PEAK_TOPS, 4),
-            "ops_per_cell": ops_cell, "fill_ms": round(fill_s * 1e3, 3),     # bulk fill launches of a step, summed (HIP events)
+            # fill_ms: the time of a step with at least one bulk fill launch in flight (HIP events around each part's launch on
+            # its stream, the union of the intervals: consecutive parts' launches overlap, the next one's waves taking the SIMDs
+            # the retiring one's leave); fill_launch_sum_ms counts such a stretch once per launch
+            "ops_per_cell": ops_cell, "fill_ms": round(fill_s * 1e3, 3), "fill_launch_sum_ms": round(fill_sum[0] / args.steps, 3),
             "fill_gcups": round(cells_step / fill_s / 1e9, 2),
             "traffic": traffic,
             "alone": alone,

@@ -81,7 +81,7 @@ class Timing(C.Structure):
     _fields_ = [("fill_ms", C.c_float), ("traceback_ms", C.c_float), ("total_ms", C.c_float),
                 ("fill_launches", C.c_uint32), ("cells", C.c_uint64), ("rows", C.c_uint64),
                 ("record_bytes", C.c_uint64), ("wide_pairs", C.c_uint32), ("scratch_retries", C.c_uint32),
-                ("device_bytes", C.c_uint64), ("slot_bytes", C.c_uint64)]
+                ("device_bytes", C.c_uint64), ("slot_bytes", C.c_uint64), ("fill_busy_ms", C.c_float)]
 
 
 class SdpParams(C.Structure):

@@ -236,6 +236,8 @@ typedef struct {
                                    kinds, the resident reference, device copies of host batches) ... */
     uint64_t slot_bytes;        /* ... of which the scratch of the part pipeline (guide stream, target codes, traceback
                                    records, block scratch; three parts in flight) */
+    float fill_busy_ms;         /* time with at least one of those bulk fill launches in flight: the union of the intervals
+                                   that fill_ms sums (launches of consecutive parts overlap; equal to fill_ms for one part) */
 } gba_timing;
 
 /* Replaces the per-thread `MappingBuffers mappingBuffers;` (Blasr.cpp:771): device
