@@ -276,7 +276,7 @@ __global__ void k_meta(Dev d, int mode, int kband_k, uint32_t score_a, uint32_t 
     if (st == GBA_PAIR_OK && (Q > (mode == GBA_MODE_AFFINE ? MAX_ROWS_AFFINE : MAX_ROWS) || T > MAX_COLS)) st = GBA_PAIR_TOO_LONG;
     if (st == GBA_PAIR_OK && (uint64_t)Q * (128u + score_a) + (uint64_t)T * score_b >= score_lim) st = GBA_PAIR_TOO_LONG;
     // the lane-per-pair fill of a batch with a cost profile puts the bias on the columns instead of the rows
-    if (st == GBA_PAIR_OK && d.prof && mode != GBA_MODE_AFFINE && (uint64_t)Q * score_a + (uint64_t)T * (128u + score_b) >= score_lim) st = GBA_PAIR_TOO_LONG;
+    if (st == GBA_PAIR_OK && d.prof && (uint64_t)Q * score_a + (uint64_t)T * (128u + score_b) >= score_lim) st = GBA_PAIR_TOO_LONG;
     d.status[p] = st; d.qS[p] = qS; d.tS[p] = tS; d.Q[p] = Q; d.T[p] = T;
     d.rows[p] = st == GBA_PAIR_OK ? Q + 1 : 0;
     d.cols[p] = st == GBA_PAIR_OK ? T + 1 : 0;
@@ -768,24 +768,24 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // are score << 6 | arrow << 3 | low bits; the gap states put their own open/extend bit in bit 2
 // (I) and bit 1 (D).  Records hold one byte per cell: M arrow (bits 3..5), I bit, D bit.
 //
-// Quality-value variant (QV, linear gaps): the costs of a row come from the cost profile of its query base (Dev.prof:
-// five substitution costs, the insertion cost, five deletion costs, each taken within +-127), fetched by the lane one
+// Quality-value variant (QV; linear gaps, and affine gaps with the gap states' constants moved the same way): the costs of a row come from the cost profile of its query base (Dev.prof:
+// five substitution costs, the insertion cost, five deletion costs, each taken within +-127, affine +-63), fetched by the lane one
 // row ahead, when it takes the row before, and turned into two byte tables for v_perm_b32 (substitution and deletion
 // by target code) and one addend (insertion) when the row is taken.  A table byte cannot be negative, so the deletion
 // costs carry a bias of 128 like the substitution costs: the bias of a cell is 128 x its COLUMN here (a diagonal move and
 // a move along the row add it, a move to the next row does not), where the matrix scorer's words carry 128 x the row.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t qv_bytes(uint32_t two)       // two int16 costs -> each within +-127, plus 128
+template <int LIM>
+__device__ __forceinline__ uint32_t qv_bytes(uint32_t two)       // two int16 costs -> each within +-LIM, plus 128
 {
     s16x2 x = __builtin_bit_cast(s16x2, two);
-    x = __builtin_elementwise_min(__builtin_elementwise_max(x, (s16x2)(short)-127), (s16x2)(short)127) + (s16x2)(short)128;
+    x = __builtin_elementwise_min(__builtin_elementwise_max(x, (s16x2)(short)-LIM), (s16x2)(short)LIM) + (s16x2)(short)128;
     return __builtin_bit_cast(uint32_t, x);
 }
 
 template <bool AFF, bool QV = false>
 __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, uint32_t slots)
 {
-    static_assert(!(AFF && QV), "the affine quality-value DP runs one wave per pair");
     extern __shared__ uint32_t smem[];
     // Claims 200 of a SIMD's 512 VGPRs per wave, so that at most two fill waves (of any class) share
     // a SIMD and a wave of another kernel still fits beside them.  LDS would admit a third fill wave
@@ -839,7 +839,9 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
         }
     }
     const uint32_t del0 = (uint32_t)(fc.del + 128) & 255u;
-    const int32_t codeU8 = fc.cU - ((fc.ins + 128) << 5), codeL8 = fc.cL - (fc.del << 5);
+    const int32_t codeU8 = fc.cU - ((fc.ins + 128) << SH), codeL8 = fc.cL - (fc.del << SH);
+    // affine gaps: a step of the insertion-gap state is a move to the next row (no bias here), one of the deletion-gap state a move along the row
+    const int32_t cIO = fc.cIO - (QV ? 128 << SH : 0), cIE = fc.cIE - (QV ? 128 << SH : 0), cDO = fc.cDO + (QV ? 128 << SH : 0), cDE = fc.cDE + (QV ? 128 << SH : 0);
     uint32_t dlo = 0, dhi = 0, ndlo = 0, ndhi = 0;      // deletion costs + 128 by target code, as mlo / mhi hold the substitution costs; the next row's
     int32_t cUq = 0, ncUq = 0;                          // insertion cost << 5 | arrow code
     uint32_t rows_left = live ? Q + 1 : 0;              // rows not yet started
@@ -864,7 +866,10 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                 if constexpr (QV) {
                     const uint32_t r = Q - rows_left;           // the row taken now
                     mlo = nmlo; mhi = nmhi; dlo = ndlo; dhi = ndhi; cUq = ncUq;
-                    if (r == 0u) { dlo = del0 * 0x01010100u; dhi = del0 * 0x01010101u; }     // (row 1's costs stay where they are)
+                    if (r == 0u) {                              // (row 1's costs stay where they are)
+                        dlo = del0 * 0x01010100u; dhi = del0 * 0x01010101u;
+                        if constexpr (AFF) { mlo = fc.mrow[8]; mhi = fc.mrow[9]; }     // the boundary row's query code is N: cell (0, 0) costs 0
+                    }
                     else if (r < Q) {                           // row r + 1 takes the costs of query base r
                         const char *nx = prow + 22u * r;
                         pa = *(const u32u1 *)(nx); pb = *(const u32u1 *)(nx + 4); pc = *(const u32u1 *)(nx + 8);
@@ -955,9 +960,9 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                                 left = cw;
                             } else {
                                 // gap states: open from the match state (preferred on ties) or extend
-                                const int32_t io = (int32_t)(u_ & ~TAGS) + fc.cIO, ie = (int32_t)ui[G & 1][x] + fc.cIE;
+                                const int32_t io = (int32_t)(u_ & ~TAGS) + cIO, ie = (int32_t)ui[G & 1][x] + cIE;
                                 const uint32_t ig = (uint32_t)min(io, ie);                 // bit 2: 1 = extend
-                                const int32_t dop = (int32_t)left + fc.cDO, de = (int32_t)leftD + fc.cDE;
+                                const int32_t dop = (int32_t)left + cDO, de = (int32_t)leftD + cDE;
                                 const uint32_t dg = (uint32_t)min(dop, de);                // bit 1: 1 = extend
                                 const int32_t dc = (int32_t)dg + (3 << 3), ic = (int32_t)ig + (4 << 3);
                                 const uint32_t best = (uint32_t)min(min(m, min(u, l)), min(dc, ic));
@@ -979,11 +984,12 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                 // The tables of the lane's next row from what it fetched when it took the current one -- here, by every lane
                 // in every step (a lane that took no row this step gets what it had), and not where the next row is taken:
                 // a use there would wait for this step's record store as well, which is younger than the fetch.
-                const uint32_t a = qv_bytes(pa), b = qv_bytes(pb), c = qv_bytes(pc), e = qv_bytes(pd), f = qv_bytes(pe), g = qv_bytes(pf);
+                constexpr int LIM = AFF ? 63 : 127;
+                const uint32_t a = qv_bytes<LIM>(pa), b = qv_bytes<LIM>(pb), c = qv_bytes<LIM>(pc), e = qv_bytes<LIM>(pd), f = qv_bytes<LIM>(pe), g = qv_bytes<LIM>(pf);
                 // byte 0 of the low word stays zero (the lookup's unused selector bytes read it); codes 5..7 read N's cost
                 nmlo = __builtin_amdgcn_perm(b, a, 0x0402000cu); nmhi = __builtin_amdgcn_perm(c, b, 0x04040402u);
                 ndlo = __builtin_amdgcn_perm(f, e, 0x0402000cu); ndhi = __builtin_amdgcn_perm(g, f, 0x04040402u);
-                ncUq = (int32_t)((c >> 16) << 5) + (codeU8 - 4096);
+                ncUq = (int32_t)((c >> 16) << SH) + (codeU8 - (128 << SH));
             }
             if (did) {
                 // record: the arrow dwords of this step (stored whole; the tail past the row end is
@@ -2889,6 +2895,7 @@ struct gba_ctx {
     // device (env GBA_SLOTS_DEVICE) and host-buffer batches (env GBA_SLOTS_HOST); 2 .. NSLOT
     uint32_t slots_device = NSLOT, slots_host = 2;
     uint32_t edge_frac = 4;          // eighths of a part the first part of a device-resident batch of three parts or more gets (env GBA_EDGE_PARTS; 0: all parts equal)
+    std::vector<uint32_t> part_shape;   // env GBA_PART_SHAPE (experiments): relative sizes of the parts of a device-resident batch, "1,2,2,2,1"
     bool alone_on_device = true;     // no other context of the process had a batch in flight on the device when this one began
     bool fill_chain = false;         // a part's fill launches wait for the end of the bulk fill of the part before (env GBA_FILL_CHAIN)
     uint32_t scratch_retries = 0;    // batches repeated with full-size block scratch
@@ -2980,20 +2987,30 @@ void release(Buf &b)
     b.ptr = nullptr; b.cap = 0;
 }
 
+// Slots of the widest lane class.  Affine gaps: a third class only where asked for (gba_ctx::affine_top_slots), and for batches
+// with a cost profile, whose wave-per-pair kernel composes a min-plus map per column and is four times slower than the plain one.
+uint32_t top_lane_slots(const gba_ctx *c, const Dev &d)
+{
+    if (c->sc.mode != GBA_MODE_AFFINE) return 128u;
+    return c->affine_top_slots ? c->affine_top_slots : d.prof ? 128u : 0u;
+}
+
 int launch_fill(gba_ctx *c, const Dev &d, uint32_t cls, uint32_t count, hipStream_t st)
 {
     const bool aff = c->sc.mode == GBA_MODE_AFFINE;
-    const uint32_t slots = cls_slots((int)cls, aff ? c->affine_top_slots : 128u);
+    const uint32_t slots = cls_slots((int)cls, top_lane_slots(c, d));
     const size_t rings = aff ? 2 : 1;
     const size_t lds = (rings * (slots + PAD_SLOTS) * 64 + LDS_TAB) * 4;
     if (!c->lds_attr_set) {                     // per device, and a ctx lives on one device
         HIPCHK(c, hipFuncSetAttribute((const void *)k_fill<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_fill<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(c, hipFuncSetAttribute((const void *)(k_fill<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(c, hipFuncSetAttribute((const void *)(k_fill<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         c->lds_attr_set = true;
     }
     const dim3 grid((count + 63) / 64), block(64);
-    if (aff) hipLaunchKernelGGL(k_fill<true>, grid, block, lds, st, d, c->fc, cls, slots);
+    if (aff && d.prof) hipLaunchKernelGGL((k_fill<true, true>), grid, block, lds, st, d, c->fc, cls, slots);
+    else if (aff) hipLaunchKernelGGL(k_fill<true>, grid, block, lds, st, d, c->fc, cls, slots);
     else if (d.prof) hipLaunchKernelGGL((k_fill<false, true>), grid, block, lds, st, d, c->fc, cls, slots);
     else hipLaunchKernelGGL(k_fill<false>, grid, block, lds, st, d, c->fc, cls, slots);
     HIPCHK(c, hipGetLastError());
@@ -3059,9 +3076,9 @@ int phase_guide(gba_ctx *c, Slot &sl, Dev &d)
     // pairs the whole batch runs one wave per pair.
     const bool affine = sc.mode == GBA_MODE_AFFINE;
     const bool local = sc.align_type == GBA_ALIGN_LOCAL;      // the free-start / best-cell end rule lives in the wave-per-pair kernels
-    const int lane_classes = local || (d.prof && affine) || d.n < (affine ? c->wave_pairs_affine : c->wave_pairs) ? 0      // affine gaps with quality-value costs: the wave-per-pair kernels have them
-                           : affine ? (c->affine_top_slots ? LANE_CLS_AFFINE + 1 : LANE_CLS_AFFINE) : LANE_CLS_LINEAR;
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(SCAN_T), 0, sl.s, d, lane_classes, 1, affine ? c->affine_top_slots : 128u);
+    const int lane_classes = local || d.n < (affine ? c->wave_pairs_affine : c->wave_pairs) ? 0
+                           : affine ? (top_lane_slots(c, d) ? LANE_CLS_AFFINE + 1 : LANE_CLS_AFFINE) : LANE_CLS_LINEAR;
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(SCAN_T), 0, sl.s, d, lane_classes, 1, top_lane_slots(c, d));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(sl.h_plan, d.plan, sizeof(Plan), hipMemcpyDeviceToHost, sl.s));
     return GBA_OK;
@@ -3433,7 +3450,16 @@ int run_device_once(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io
     {
         const uint32_t head = c->edge_frac && c->alone_on_device && !io && parts >= 3 ? (uint32_t)(((uint64_t)per * c->edge_frac / 8 + 63) & ~63ull) : per;
         bound.push_back(0);
-        for (uint64_t x = head; x < n; x += per) bound.push_back((uint32_t)x);
+        if (!c->part_shape.empty() && !io && parts >= 3) {       // experiments: parts in the proportions of GBA_PART_SHAPE
+            uint64_t total = 0, cum = 0;
+            for (uint32_t w : c->part_shape) total += w;
+            for (size_t i = 0; i + 1 < c->part_shape.size(); i++) {
+                cum += c->part_shape[i];
+                const uint32_t x = (uint32_t)(((uint64_t)n * cum / total + 63) & ~63ull);
+                if (x > bound.back() && x < n) bound.push_back(x);
+            }
+        } else
+            for (uint64_t x = head; x < n; x += per) bound.push_back((uint32_t)x);
         bound.push_back(n);
         parts = (uint32_t)bound.size() - 1;
     }
@@ -3736,6 +3762,16 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
         }
         if (const char *e = getenv("GBA_SLOTS_DEVICE")) { const int v = atoi(e); if (v >= 2 && v <= NSLOT) c->slots_device = (uint32_t)v; }
         if (const char *e = getenv("GBA_FILL_CHAIN")) c->fill_chain = atoi(e) != 0;
+        if (const char *e = getenv("GBA_PART_SHAPE")) {
+            for (const char *q = e; *q;) {
+                char *end = nullptr;
+                const unsigned long v = strtoul(q, &end, 10);
+                if (end == q) break;
+                if (v > 0 && v < 1000) c->part_shape.push_back((uint32_t)v);
+                q = *end == ',' ? end + 1 : end;
+                if (*end && *end != ',') break;
+            }
+        }
         if (const char *e = getenv("GBA_EDGE_PARTS")) { const int v = atoi(e); if (v >= 0 && v < 8) c->edge_frac = (uint32_t)v; }
         if (const char *e = getenv("GBA_SLOTS_HOST")) { const int v = atoi(e); if (v >= 2 && v <= NSLOT) c->slots_host = (uint32_t)v; }
         if (const char *e = getenv("GBA_BLK_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 1024) c->blk_div = (uint32_t)v; }

@@ -98,17 +98,20 @@ def test_profile_with_the_kband_geometry(oracle, synth, monkeypatch, k, family):
     ctx.close()
 
 
+@pytest.mark.parametrize("family", ["lane-per-pair", "wave-per-pair"])
 @pytest.mark.parametrize("band,oe", [(8, (4, 1)), (16, (10, 0)), (150, (3, 2)), (40, (0, 7))])
-def test_profile_costs_with_affine_gaps(oracle, synth, band, oe):
+def test_profile_costs_with_affine_gaps(oracle, synth, monkeypatch, band, oe, family):
     """AffineGuidedAlign with the IDS scorer (/root/reference/iblasr/BlasrUtilsImpl.hpp:707-710): per-base costs for
     substitution, insertion and the one-base deletion (taken within +-63), constant gap open / extend; narrow and wide
-    rows, both tie-breaks, an extend cost above and below the per-base deletion costs, host and device batches."""
+    rows, both tie-breaks, an extend cost above and below the per-base deletion costs, host and device batches; one
+    lane per pair (k_fill<true, true>, the pairs narrow enough for a lane class) and one wave per pair."""
     import torch
     from blasr_amd import api, _lib
     rng = np.random.default_rng(17 + band)
     batch = synth.compact_blocks(synth.generate(96, read_len=800, len_jitter=500, seed=3 + band))
     prof = _profile(rng, batch)
-    ctx = api.Context(0)
+    monkeypatch.setenv("GBA_WAVE_PAIRS_AFFINE", "1" if family == "lane-per-pair" else "4000000000")
+    ctx = api.Context(0, timing=True)
     for tie in (0, 1):
         kw = dict(mode=_lib.MODE_AFFINE, band=band, tie_break=tie, ins=5, dele=4, affine_open=oe[0], affine_extend=oe[1],
                   stats_affine=1, stats_affine_open=2, stats_affine_extend=1)
@@ -116,6 +119,8 @@ def test_profile_costs_with_affine_gaps(oracle, synth, band, oe):
         with_prof = dict(batch, q_profile=prof)
         pairs, blocks, rc = ctx.refine_host(with_prof)
         assert rc == 0 and int((pairs["status"] == 0).sum()) == 96
+        wide = int(ctx.timing()["wide_pairs"])
+        assert wide == 96 if family == "wave-per-pair" or band > 40 else wide < 48, wide        # with a profile affine batches have a 128-slot lane class
         _check(oracle, batch, prof, oracle.make_params(**kw), pairs, blocks)
     plain, _, _ = ctx.refine_host(batch)
     assert (plain["dp_score"] != pairs["dp_score"]).any()
@@ -128,7 +133,7 @@ def test_profile_costs_with_affine_gaps(oracle, synth, band, oe):
     ctx.close()
 
 
-def test_affine_profile_that_spells_out_the_matrix_gives_the_plain_affine_results(synth):
+def test_affine_profile_that_spells_out_the_matrix_gives_the_plain_affine_results(synth, monkeypatch):
     """A profile whose costs are the matrix row of each base, ins and del: the composed-map row scan of the
     quality-value kernel reproduces the two-slope scan of the plain affine kernel (no oracle involved), reads of 6 kb."""
     from blasr_amd import api, _lib
@@ -145,13 +150,15 @@ def test_affine_profile_that_spells_out_the_matrix_gives_the_plain_affine_result
     prof[:, :5] = sub[qc]
     prof[:, 5] = kw["ins"]
     prof[:, 6:] = kw["dele"]
-    ctx = api.Context(0)
-    ctx.set_scoring(sc)
-    a = ctx.refine_host(host)
-    b = ctx.refine_host(dict(host, q_profile=prof.reshape(-1)))
-    assert a[2] == 0 and b[2] == 0 and int((a[0]["status"] == 0).sum()) == n
-    assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
-    ctx.close()
+    for wave_pairs in ("4000000000", "1"):          # one wave per pair, then the lane classes
+        monkeypatch.setenv("GBA_WAVE_PAIRS_AFFINE", wave_pairs)
+        ctx = api.Context(0)
+        ctx.set_scoring(sc)
+        a = ctx.refine_host(host)
+        b = ctx.refine_host(dict(host, q_profile=prof.reshape(-1)))
+        assert a[2] == 0 and b[2] == 0 and int((a[0]["status"] == 0).sum()) == n
+        assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+        ctx.close()
 
 
 @pytest.mark.parametrize("affine", [False, True])

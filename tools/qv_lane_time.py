@@ -1,5 +1,6 @@
 """The guided DP (linear gaps) with a quality-value profile on the lane-per-pair kernel (k_fill<false, true>) against the
-wave-per-pair kernels (GBA_WAVE_PAIRS raised) and the matrix scorer, device-resident.  usage: qv_lane_time.py pairs ..."""
+wave-per-pair kernels (GBA_WAVE_PAIRS raised) and the matrix scorer, device-resident.  usage: qv_lane_time.py [affine] pairs ...
+(affine: band 16, open 6, extend 2, k_fill<true, true>)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,7 +8,10 @@ sys.path.insert(0, ROOT)
 import torch
 from blasr_amd import api, synth, _lib
 
-for n in [int(a) for a in sys.argv[1:]] or [32768]:
+AFFINE = len(sys.argv) > 1 and sys.argv[1] == "affine"
+KW = dict(mode=_lib.MODE_AFFINE, band=16, affine_open=6, affine_extend=2, stats_affine=1) if AFFINE else {}
+ENV = "GBA_WAVE_PAIRS_AFFINE" if AFFINE else "GBA_WAVE_PAIRS"
+for n in [int(a) for a in sys.argv[1:] if a != "affine"] or [32768]:
     host = synth.compact_blocks(synth.preset("c2_10kb_linear", n)[0])
     d = api.to_device(host)
     na = len(host["q_arena"])
@@ -24,11 +28,11 @@ for n in [int(a) for a in sys.argv[1:]] or [32768]:
     for name, b, wave_pairs in (("matrix scorer", d, None), ("quality-value profile, lane classes", dp, None),
                                 ("quality-value profile, one wave per pair", dp, "4000000000")):
         if wave_pairs:
-            os.environ["GBA_WAVE_PAIRS"] = wave_pairs
+            os.environ[ENV] = wave_pairs
         else:
-            os.environ.pop("GBA_WAVE_PAIRS", None)
+            os.environ.pop(ENV, None)
         ctx = api.Context(0, timing=True)
-        ctx.set_scoring(api.make_scoring())
+        ctx.set_scoring(api.make_scoring(**KW))
         ctx.refine_device(b, out_pairs, out_blocks)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
