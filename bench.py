@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 
 # HBM bytes of one step's fill launches at the default workload, from separate rocprofv3 --pmc passes of
 # this command (profiles/, WRITE_SIZE + 2 x FETCH_SIZE: the gfx950 correction for streamed reads)
-MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 491520): 147829239 * 1024 + 2 * 19575698 * 1024}
+MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 491520): 136421023 * 1024 + 2 * 18475953 * 1024}
 OPS_PER_CELL = {"linear": 8, "affine": 18}         # algorithmic int32 ops per DP cell
 BYTES_PER_CELL = {"linear": 0.25, "affine": 0.75}  # algorithmic traceback bytes per cell
 VALU_PEAK_TOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz int32 lane-ops/s (= half the 157.3 TFLOP/s fp32 vector peak)
@@ -255,7 +255,7 @@ def kernel_name(cfg, tm, n, quad_min, qv=False):
         if affine:
             return "k_fill_quad_affine" if tm["wide_pairs"] >= quad_min and cfg["band"] <= 30 else "k_fill_wide_affine"
         return "k_fill_wide_cols" if cfg["band"] > 30 else "k_fill_wide<1>"
-    return "k_fill<%s>" % ("true" if affine else "false")
+    return "k_fill<%s, false>" % ("true" if affine else "false")
 
 
 def stream_batches(torch, pipe, dbatch, bufs, warm, count):

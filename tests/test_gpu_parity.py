@@ -564,6 +564,55 @@ def test_batches_in_parts(api, oracle, synth, monkeypatch, part):
         c2.close()
 
 
+@pytest.mark.parametrize("edge", ["4", "2", "0"])
+def test_device_batches_with_small_first_and_last_parts(api, synth, monkeypatch, edge):
+    """A device-resident batch of three parts or more gets a small first and last part (GBA_EDGE_PARTS eighths of a
+    part; 0: equal parts) when its context has the GPU to itself: pair results and the packed block arena are those of
+    the host-buffer path, whose parts are equal; a second context with a batch in flight at the same time gets equal
+    parts, and the same bytes."""
+    import threading
+    import torch
+    from blasr_amd import _lib
+    monkeypatch.setenv("GBA_PART_PAIRS", "128")
+    monkeypatch.setenv("GBA_EDGE_PARTS", edge)
+    n = 900
+    batch = synth.generate(n, read_len=1500, len_jitter=900, seed=606, decoy_every=6)
+    ctxs = [api.Context(0), api.Context(0)]
+    try:
+        for c in ctxs:
+            c.set_scoring(api.make_scoring())
+        want, wblk, rc = ctxs[0].refine_host(batch)
+        assert rc == 0
+        d = api.to_device(batch)
+        outs = [(torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0"),
+                 torch.zeros((len(wblk) + 8, 3), dtype=torch.int32, device="cuda:0")) for _ in ctxs]
+        rc, needed = ctxs[0].refine_device(d, *outs[0])
+        torch.cuda.synchronize()
+        assert rc == 0 and needed == len(wblk)
+        assert outs[0][0].cpu().numpy().tobytes() == want.tobytes()
+        assert outs[0][1][:needed].cpu().numpy().tobytes() == wblk.tobytes()
+        for o in outs:
+            o[0].zero_(); o[1].zero_()
+        got = [None, None]
+
+        def run(i):
+            for _ in range(3):
+                got[i] = ctxs[i].refine_device(d, *outs[i])
+        th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        for i in range(2):
+            assert got[i] == (0, len(wblk))
+            assert outs[i][0].cpu().numpy().tobytes() == want.tobytes()
+            assert outs[i][1][:len(wblk)].cpu().numpy().tobytes() == wblk.tobytes()
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_host_batches_pinned_async_and_out_of_order(api, oracle, synth, monkeypatch):
     """gba_submit returns before the batch has run; batches and results in page-locked memory of
     the ctx; arenas whose pairs are NOT laid out in pair order (each part of the batch then needs
