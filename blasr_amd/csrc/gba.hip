@@ -2894,7 +2894,7 @@ struct gba_ctx {
     // slots of the part pipeline a batch uses (each holds the scratch of one part): batches whose buffers are on the
     // device (env GBA_SLOTS_DEVICE) and host-buffer batches (env GBA_SLOTS_HOST); 2 .. NSLOT
     uint32_t slots_device = NSLOT, slots_host = 2;
-    uint32_t edge_frac = 4;          // eighths of a part the first part of a device-resident batch of three parts or more gets (env GBA_EDGE_PARTS; 0: all parts equal)
+    uint32_t edge_frac = 1;          // a context that has the GPU to itself shapes the parts of a device-resident batch for its head and tail (run_device_once; env GBA_EDGE_PARTS=0: equal parts always)
     std::vector<uint32_t> part_shape;   // env GBA_PART_SHAPE (experiments): relative sizes of the parts of a device-resident batch, "1,2,2,2,1"
     bool alone_on_device = true;     // no other context of the process had a batch in flight on the device when this one began
     bool fill_chain = false;         // a part's fill launches wait for the end of the bulk fill of the part before (env GBA_FILL_CHAIN)
@@ -3440,26 +3440,42 @@ int run_device_once(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io
     }
     const uint32_t per = (uint32_t)((((uint64_t)n + parts - 1) / parts + 63) & ~63ull);     // whole waves
     parts = (n + per - 1) / per;
-    // part h is pairs [bound[h], bound[h + 1]).  edge_parts (device-resident batches of three parts or more): the boundaries
-    // are moved by edge_frac of a part, so that the first and the last part are small: the first fill starts sooner,
-    // and the last traceback, which nothing runs beside, has fewer waves.  Measured on 491 520 pairs of 10 kb: 858-875
-    // GCUPS against 823-850 with equal parts.  Not when another context has a batch in flight on the GPU (a caller that
-    // streams batches through two contexts): that batch's kernels fill the head and the tail already, and the fifth
-    // part only costs (864-879 against 897-899).
+    // part h is pairs [bound[h], bound[h + 1]).  Batches from host buffers, and device-resident batches of a context that shares
+    // the GPU with another context's batch (a caller that streams batches through two contexts), run in equal parts of about
+    // part_pairs: the other batch's kernels fill this one's head (the first part's packing and guide, nothing else to run) and
+    // tail (the last part's traceback).  A context that has the GPU to itself shapes a device-resident batch for its own head
+    // and tail (edge_frac != 0): up to 1.7 x part_pairs two halves, beyond that the fewest parts P >= 3 in the proportions
+    // 3 : 4 : ... : 4 : 3 whose middle parts stay below 1.04 x part_pairs.  The first fill starts sooner and shares the SIMDs
+    // with the second part's as soon as that is ready (parts a little below two waves per SIMD leave room for the next one's
+    // first waves), and the last traceback has fewer waves.  Measured on pairs of 10 kb, GCUPS with these parts / with equal
+    // parts of about part_pairs (tools/run_shape2.sh): 245 760 pairs 796 / 707, 307 200: 813 / 796, 368 640: 821-842 / 788,
+    // 491 520: 856-875 / 823-850, 614 400: 881 / 848; parts below 90 000 pairs lose (fewer than 1.4 waves per SIMD).
     std::vector<uint32_t> bound;
     {
-        const uint32_t head = c->edge_frac && c->alone_on_device && !io && parts >= 3 ? (uint32_t)(((uint64_t)per * c->edge_frac / 8 + 63) & ~63ull) : per;
         bound.push_back(0);
-        if (!c->part_shape.empty() && !io && parts >= 3) {       // experiments: parts in the proportions of GBA_PART_SHAPE
+        std::vector<uint32_t> shape;
+        if (!io && !c->fixed_on && c->part_pairs) {
+            if (!c->part_shape.empty()) shape = c->part_shape;       // experiments: parts in the proportions of GBA_PART_SHAPE
+            else if (c->edge_frac && c->alone_on_device && parts >= 2) {
+                if ((uint64_t)n * 10 <= (uint64_t)c->part_pairs * 17) shape = {1, 1};
+                else {
+                    uint32_t P = 3;
+                    while ((uint64_t)n * 2 * 24 > (uint64_t)c->part_pairs * 25 * (2 * P - 1)) P++;      // n / (P - 1/2) <= 25/24 part_pairs
+                    shape.assign(P, 4);
+                    shape.front() = shape.back() = 3;
+                }
+            }
+        }
+        if (!shape.empty()) {
             uint64_t total = 0, cum = 0;
-            for (uint32_t w : c->part_shape) total += w;
-            for (size_t i = 0; i + 1 < c->part_shape.size(); i++) {
-                cum += c->part_shape[i];
+            for (uint32_t w : shape) total += w;
+            for (size_t i = 0; i + 1 < shape.size(); i++) {
+                cum += shape[i];
                 const uint32_t x = (uint32_t)(((uint64_t)n * cum / total + 63) & ~63ull);
                 if (x > bound.back() && x < n) bound.push_back(x);
             }
         } else
-            for (uint64_t x = head; x < n; x += per) bound.push_back((uint32_t)x);
+            for (uint64_t x = per; x < n; x += per) bound.push_back((uint32_t)x);
         bound.push_back(n);
         parts = (uint32_t)bound.size() - 1;
     }
@@ -3772,7 +3788,7 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
                 if (*end && *end != ',') break;
             }
         }
-        if (const char *e = getenv("GBA_EDGE_PARTS")) { const int v = atoi(e); if (v >= 0 && v < 8) c->edge_frac = (uint32_t)v; }
+        if (const char *e = getenv("GBA_EDGE_PARTS")) c->edge_frac = atoi(e) != 0;
         if (const char *e = getenv("GBA_SLOTS_HOST")) { const int v = atoi(e); if (v >= 2 && v <= NSLOT) c->slots_host = (uint32_t)v; }
         if (const char *e = getenv("GBA_BLK_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 1024) c->blk_div = (uint32_t)v; }
         if (const char *e = getenv("GBA_BLK_POOL_DIV")) { const int v = atoi(e); if (v >= 1 && v <= (1 << 20)) c->blk_pool_div = (uint32_t)v; }

@@ -564,16 +564,16 @@ def test_batches_in_parts(api, oracle, synth, monkeypatch, part):
         c2.close()
 
 
-@pytest.mark.parametrize("edge", ["4", "2", "0"])
-def test_device_batches_with_small_first_and_last_parts(api, synth, monkeypatch, edge):
-    """A device-resident batch of three parts or more gets a small first and last part (GBA_EDGE_PARTS eighths of a
-    part; 0: equal parts) when its context has the GPU to itself: pair results and the packed block arena are those of
-    the host-buffer path, whose parts are equal; a second context with a batch in flight at the same time gets equal
+@pytest.mark.parametrize("edge,part", [("1", "128"), ("1", "600"), ("1", "400"), ("0", "128")])
+def test_device_batches_with_small_first_and_last_parts(api, synth, monkeypatch, edge, part):
+    """A context that has the GPU to itself cuts a device-resident batch into parts of its own shape (two halves, or
+    3 : 4 : ... : 4 : 3; GBA_EDGE_PARTS=0: equal parts): pair results and the packed block arena are those of the
+    host-buffer path, whose parts are equal; a second context with a batch in flight at the same time gets equal
     parts, and the same bytes."""
     import threading
     import torch
     from blasr_amd import _lib
-    monkeypatch.setenv("GBA_PART_PAIRS", "128")
+    monkeypatch.setenv("GBA_PART_PAIRS", part)
     monkeypatch.setenv("GBA_EDGE_PARTS", edge)
     n = 900
     batch = synth.generate(n, read_len=1500, len_jitter=900, seed=606, decoy_every=6)
