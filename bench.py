@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 
 # HBM bytes of one step's fill launches at the default workload, from separate rocprofv3 --pmc passes of
 # this command (profiles/, WRITE_SIZE + 2 x FETCH_SIZE: the gfx950 correction for streamed reads)
-MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 491520): 136421023 * 1024 + 2 * 18475953 * 1024}
+MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 491520): 125906804 * 1024 + 2 * 18229433 * 1024}
 OPS_PER_CELL = {"linear": 8, "affine": 18}         # algorithmic int32 ops per DP cell
 BYTES_PER_CELL = {"linear": 0.25, "affine": 0.75}  # algorithmic traceback bytes per cell
 VALU_PEAK_TOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz int32 lane-ops/s (= half the 157.3 TFLOP/s fp32 vector peak)
