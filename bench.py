@@ -39,7 +39,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 # A context runs the parts of a batch on a dozen streams (three slots of a main and two auxiliary streams, two copy
 # streams).  With HIP's default of four hardware queues streams share queues and one part's guide construction waits
-# behind another part's fill; the library's callers are told to raise it (INTEGRATION.md), and so does this program,
+# behind another part's fill; the library's callers are told to raise it, and so does this program,
 # before the HIP runtime starts.
 os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("GBA_BENCH_HW_QUEUES", "16")      # (the GPU boxes export the default, 4)
 sys.path.insert(0, ROOT)

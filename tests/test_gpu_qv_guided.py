@@ -275,12 +275,14 @@ def test_a_profile_that_spells_out_the_matrix_gives_the_plain_results(synth, mon
     assert outs[0][2] < n // 2 and outs[1][2] == outs[0][2] and outs[2][2] == n
 
 
-def test_score_range_guard_counts_the_profile_costs(oracle, synth):
+@pytest.mark.parametrize("family", ["lane-per-pair", "wave-per-pair"])
+def test_score_range_guard_counts_the_profile_costs(oracle, synth, monkeypatch, family):
     """A pair near the row limit whose profile holds the largest costs the kernels take: its scores would leave the
     cell word (rows x (128 + 127) + columns x 127, or rows x 127 + columns x (128 + 127), reaches 2^24), so it comes back
     TOO_LONG instead of a wrapped score;
     a shorter one with the same costs fits and agrees with the oracle."""
     from blasr_amd import api, _lib
+    monkeypatch.setenv("GBA_WAVE_PAIRS", "1" if family == "lane-per-pair" else "4000000000")
     ctx = api.Context(0)
     kw = dict(band=10, ins=5, dele=4)
     ctx.set_scoring(api.make_scoring(**kw))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copies what tools/r03_final.sh left under gpurun_out/ into profiles/ under the names DESIGN.md cites.
+# Copies what tools/r03_final.sh left under gpurun_out/ into profiles/ under the names the closing measurements have there.
 set -e
 cd "$(dirname "$0")/.."
 g=gpurun_out; p=profiles
