@@ -768,12 +768,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // are score << 6 | arrow << 3 | low bits; the gap states put their own open/extend bit in bit 2
 // (I) and bit 1 (D).  Records hold one byte per cell: M arrow (bits 3..5), I bit, D bit.
 //
-// Quality-value variant (QV; linear gaps, and affine gaps with the gap states' constants moved the same way): the costs of a row come from the cost profile of its query base (Dev.prof:
-// five substitution costs, the insertion cost, five deletion costs, each taken within +-127, affine +-63), fetched by the lane one
-// row ahead, when it takes the row before, and turned into two byte tables for v_perm_b32 (substitution and deletion
-// by target code) and one addend (insertion) when the row is taken.  A table byte cannot be negative, so the deletion
-// costs carry a bias of 128 like the substitution costs: the bias of a cell is 128 x its COLUMN here (a diagonal move and
-// a move along the row add it, a move to the next row does not), where the matrix scorer's words carry 128 x the row.
+// Quality-value variant (QV; linear gaps, and affine gaps with the constants of the gap states moved the same way): the
+// costs of a row come from the cost profile of its query base (Dev.prof: five substitution costs, the insertion cost,
+// five deletion costs, each taken within +-127, affine +-63).  A lane fetches the 22 bytes of its next row when it takes
+// a row, and at the end of every step every lane turns what it has fetched into two byte tables for v_perm_b32
+// (substitution and deletion cost by target code) and one addend (insertion), which the next row takes over.  A table
+// byte cannot be negative, so the deletion costs carry a bias of 128 like the substitution costs: the bias of a cell is
+// 128 x its COLUMN here (a diagonal move and a move along the row add it, a move to the next row does not), where the
+// matrix scorer's words carry 128 x the row.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 template <int LIM>
 __device__ __forceinline__ uint32_t qv_bytes(uint32_t two)       // two int16 costs -> each within +-LIM, plus 128
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     // affine gaps: a step of the insertion-gap state is a move to the next row (no bias here), one of the deletion-gap state a move along the row
     const int32_t cIO = fc.cIO - (QV ? 128 << SH : 0), cIE = fc.cIE - (QV ? 128 << SH : 0), cDO = fc.cDO + (QV ? 128 << SH : 0), cDE = fc.cDE + (QV ? 128 << SH : 0);
     uint32_t dlo = 0, dhi = 0, ndlo = 0, ndhi = 0;      // deletion costs + 128 by target code, as mlo / mhi hold the substitution costs; the next row's
-    int32_t cUq = 0, ncUq = 0;                          // insertion cost << 5 | arrow code
+    int32_t cUq = 0, ncUq = 0;                          // insertion cost << SH | arrow code
     uint32_t rows_left = live ? Q + 1 : 0;              // rows not yet started
     uint32_t W = 0, dsh = 0, k0 = 0, Wp = 0;            // current row: width, shift, cells done; previous width
     uint32_t ext_left = 0, newslot = 0;
@@ -2894,7 +2896,7 @@ struct gba_ctx {
     // slots of the part pipeline a batch uses (each holds the scratch of one part): batches whose buffers are on the
     // device (env GBA_SLOTS_DEVICE) and host-buffer batches (env GBA_SLOTS_HOST); 2 .. NSLOT
     uint32_t slots_device = NSLOT, slots_host = 2;
-    uint32_t edge_frac = 1;          // a context that has the GPU to itself shapes the parts of a device-resident batch for its head and tail (run_device_once; env GBA_EDGE_PARTS=0: equal parts always)
+    bool shape_parts = true;          // a context that has the GPU to itself shapes the parts of a device-resident batch for its head and tail (run_device_once; env GBA_EDGE_PARTS=0: equal parts always)
     std::vector<uint32_t> part_shape;   // env GBA_PART_SHAPE (experiments): relative sizes of the parts of a device-resident batch, "1,2,2,2,1"
     bool alone_on_device = true;     // no other context of the process had a batch in flight on the device when this one began
     bool fill_chain = false;         // a part's fill launches wait for the end of the bulk fill of the part before (env GBA_FILL_CHAIN)
@@ -3444,7 +3446,7 @@ int run_device_once(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io
     // the GPU with another context's batch (a caller that streams batches through two contexts), run in equal parts of about
     // part_pairs: the other batch's kernels fill this one's head (the first part's packing and guide, nothing else to run) and
     // tail (the last part's traceback).  A context that has the GPU to itself shapes a device-resident batch for its own head
-    // and tail (edge_frac != 0): up to 1.7 x part_pairs two halves, beyond that the fewest parts P >= 3 in the proportions
+    // and tail (shape_parts): up to 1.7 x part_pairs two halves, beyond that the fewest parts P >= 3 in the proportions
     // 3 : 4 : ... : 4 : 3 whose middle parts stay below 1.04 x part_pairs.  The first fill starts sooner and shares the SIMDs
     // with the second part's as soon as that is ready (parts a little below two waves per SIMD leave room for the next one's
     // first waves), and the last traceback has fewer waves.  Measured on pairs of 10 kb, GCUPS with these parts / with equal
@@ -3456,7 +3458,7 @@ int run_device_once(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io
         std::vector<uint32_t> shape;
         if (!io && !c->fixed_on && c->part_pairs) {
             if (!c->part_shape.empty()) shape = c->part_shape;       // experiments: parts in the proportions of GBA_PART_SHAPE
-            else if (c->edge_frac && c->alone_on_device && parts >= 2) {
+            else if (c->shape_parts && c->alone_on_device && parts >= 2) {
                 if ((uint64_t)n * 10 <= (uint64_t)c->part_pairs * 17) shape = {1, 1};
                 else {
                     uint32_t P = 3;
@@ -3788,7 +3790,7 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
                 if (*end && *end != ',') break;
             }
         }
-        if (const char *e = getenv("GBA_EDGE_PARTS")) c->edge_frac = atoi(e) != 0;
+        if (const char *e = getenv("GBA_EDGE_PARTS")) c->shape_parts = atoi(e) != 0;
         if (const char *e = getenv("GBA_SLOTS_HOST")) { const int v = atoi(e); if (v >= 2 && v <= NSLOT) c->slots_host = (uint32_t)v; }
         if (const char *e = getenv("GBA_BLK_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 1024) c->blk_div = (uint32_t)v; }
         if (const char *e = getenv("GBA_BLK_POOL_DIV")) { const int v = atoi(e); if (v >= 1 && v <= (1 << 20)) c->blk_pool_div = (uint32_t)v; }
