@@ -2918,6 +2918,7 @@ struct gba_ctx {
                                          // back one wave per pair too (measured crossover: 6 600 pairs of 10 kb, 10 600 of 20 kb affine; env GBA_TB_WAVE_MAX)
     uint32_t quad_affine_min = 10240;   // narrow affine wave class: this many pairs or more run four pairs per wave (fewer leave SIMDs
                                         // without a wave that way; measured crossover between 8 192 and 12 288 pairs of 20 kb; env GBA_QUAD_AFFINE_MIN)
+    uint32_t wave_pairs_affine_prof = 24576;   // the same for affine batches with a cost profile (GBA_WAVE_PAIRS_AFFINE sets both)
     uint32_t wave_pairs = 20480, wave_pairs_affine = 57344;   // batches (parts) smaller than this run wave-per-pair (env GBA_WAVE_PAIRS, GBA_WAVE_PAIRS_AFFINE)
     uint32_t score_a = 0, score_b = 0;   // largest cost of a row move / of a move along a row (k_meta's score-range check)
     uint32_t part_pairs = 122880;    // a batch of more than ~1.07 x this many pairs is run in staggered parts of about this
@@ -3078,7 +3079,10 @@ int phase_guide(gba_ctx *c, Slot &sl, Dev &d)
     // pairs the whole batch runs one wave per pair.
     const bool affine = sc.mode == GBA_MODE_AFFINE;
     const bool local = sc.align_type == GBA_ALIGN_LOCAL;      // the free-start / best-cell end rule lives in the wave-per-pair kernels
-    const int lane_classes = local || d.n < (affine ? c->wave_pairs_affine : c->wave_pairs) ? 0
+    // (affine gaps with a cost profile: the wave-per-pair kernel composes a min-plus map per column, and the lane classes win from
+    // about 24 000 pairs of 10 kb on: 32 768 pairs 146 against 91 GCUPS, 16 384 pairs 76 against 83)
+    const uint32_t lanes_from = affine ? (d.prof ? c->wave_pairs_affine_prof : c->wave_pairs_affine) : c->wave_pairs;
+    const int lane_classes = local || d.n < lanes_from ? 0
                            : affine ? (top_lane_slots(c, d) ? LANE_CLS_AFFINE + 1 : LANE_CLS_AFFINE) : LANE_CLS_LINEAR;
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(SCAN_T), 0, sl.s, d, lane_classes, 1, top_lane_slots(c, d));
     HIPCHK(c, hipGetLastError());
@@ -3772,7 +3776,7 @@ int gba_create(gba_ctx **out, const gba_config *cfg)
         if (const char *e = getenv("GBA_TB_WAVE_MAX")) c->tb_wave_max = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_TB_FEW_MAX")) c->tb_few_max = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_QUAD_AFFINE_MIN")) c->quad_affine_min = (uint32_t)strtoul(e, nullptr, 10);
-        if (const char *e = getenv("GBA_WAVE_PAIRS_AFFINE")) c->wave_pairs_affine = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char *e = getenv("GBA_WAVE_PAIRS_AFFINE")) c->wave_pairs_affine = c->wave_pairs_affine_prof = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBA_AFFINE_TOP_SLOTS")) { const uint32_t v = (uint32_t)strtoul(e, nullptr, 10); if (v == 0 || (v > 64 && v <= 128)) c->affine_top_slots = v; }
         if (const char *e = getenv("GBA_SDP_TILE")) {
             const uint32_t v = (uint32_t)strtoul(e, nullptr, 10);

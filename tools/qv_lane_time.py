@@ -25,7 +25,8 @@ for n in [int(a) for a in sys.argv[1:] if a != "affine"] or [32768]:
     out_pairs = torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0")
     out_blocks = torch.zeros((int(host["q_len"].astype(np.int64).sum() // 4) + n, 3), dtype=torch.int32, device="cuda:0")
     digests = []
-    for name, b, wave_pairs in (("matrix scorer", d, None), ("quality-value profile, lane classes", dp, None),
+    for name, b, wave_pairs in (("matrix scorer", d, None), ("quality-value profile, the library's choice", dp, None),
+                                ("quality-value profile, lane classes whatever the batch size", dp, "1"),
                                 ("quality-value profile, one wave per pair", dp, "4000000000")):
         if wave_pairs:
             os.environ[ENV] = wave_pairs
@@ -46,6 +47,6 @@ for n in [int(a) for a in sys.argv[1:] if a != "affine"] or [32768]:
         digests.append(r.tobytes())
         print("%s: %d pairs, %.1f ms, %.1f GCUPS, ok %d, fill %.1f ms, one wave per pair %d" % (name, n, dt * 1e3, cells / dt / 1e9, int((r["status"] == 0).sum()), tm["fill_ms"], int(tm["wide_pairs"])), flush=True)
         ctx.close()
-    print("profile results equal on both kernel families:", digests[1] == digests[2], flush=True)
+    print("profile results equal on both kernel families:", digests[1] == digests[2] == digests[3], flush=True)
     del d, dp, prof, out_pairs, out_blocks
     torch.cuda.empty_cache()
