@@ -785,9 +785,17 @@ __device__ __forceinline__ uint32_t qv_bytes(uint32_t two)       // two int16 co
     return __builtin_bit_cast(uint32_t, x);
 }
 
-template <bool AFF, bool QV = false>
+//
+// LOCAL (linear gaps, matrix costs; gba_scoring.align_type GBA_ALIGN_LOCAL as in k_fill_wide): every cell may begin an
+// alignment (a fourth candidate of score 0 with the arrow code 3, last in the tie-break), row 0 has no deletion chain,
+// and the lane keeps the cheapest cell of its pair, the first in row-major order among equals: per step the minimum of
+// score | cell number over the step's cells OF THE ROW (the groups run past a row's end, and what they compute there may
+// be a real cell outside the band), compared with the best so far once the row bias is taken off.  The cell's row,
+// column, first column of its row and the meta dword of that row go to Dev::end_* for the traceback.
+template <bool AFF, bool QV = false, bool LOCAL = false>
 __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, uint32_t slots)
 {
+    static_assert(!LOCAL || (!AFF && !QV), "the Local end rule: linear gaps, matrix costs");
     extern __shared__ uint32_t smem[];
     // Claims 200 of a SIMD's 512 VGPRs per wave, so that at most two fill waves (of any class) share
     // a SIMD and a wave of another kernel still fits beside them.  LDS would admit a third fill wave
@@ -846,6 +854,12 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     const int32_t cIO = fc.cIO - (QV ? 128 << SH : 0), cIE = fc.cIE - (QV ? 128 << SH : 0), cDO = fc.cDO + (QV ? 128 << SH : 0), cDE = fc.cDE + (QV ? 128 << SH : 0);
     uint32_t dlo = 0, dhi = 0, ndlo = 0, ndhi = 0;      // deletion costs + 128 by target code, as mlo / mhi hold the substitution costs; the next row's
     int32_t cUq = 0, ncUq = 0;                          // insertion cost << SH | arrow code
+    // LOCAL: the current row's number, first column and start candidate; the cheapest cell so far (score << 5 without the
+    // row bias, row, column, first column of its row, meta dword of its row; fresh: the row of the cell has not ended yet)
+    const uint32_t rob0 = rob;
+    uint32_t rrow = 0, lo_abs = 0, bi = 0, bj = 0, blo = 0, bptr = 0;
+    int32_t startw = 3 << 3, bsc = 0;
+    bool fresh = false;
     uint32_t rows_left = live ? Q + 1 : 0;              // rows not yet started
     uint32_t W = 0, dsh = 0, k0 = 0, Wp = 0;            // current row: width, shift, cells done; previous width
     uint32_t ext_left = 0, newslot = 0;
@@ -865,6 +879,7 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                 rows_left--;
                 Wp = W;
                 W = word & ROW_W_MASK; dsh = (word >> 13) & 1023u;
+                if constexpr (LOCAL) { rrow = Q - rows_left; lo_abs += dsh; startw = (int32_t)(rrow * 4096u) + (3 << 3); }
                 if constexpr (QV) {
                     const uint32_t r = Q - rows_left;           // the row taken now
                     mlo = nmlo; mhi = nmhi; dlo = ndlo; dhi = ndhi; cUq = ncUq;
@@ -905,6 +920,7 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
             uint32_t ar[NAR];
     #pragma unroll
             for (int x = 0; x < NAR; x++) ar[x] = 0;
+            int32_t stepmin = 0x7fffffff;               // LOCAL: cheapest cell of the row in this step, score | cell number within the step
             // One LDS round trip for everything the step's first cells need: the diagonal predecessor of
             // a new row's first cell and the vertical predecessors of the first 8 cells (lanes without
             // cells this step read slots 0..7, which always exist).
@@ -920,7 +936,8 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                     if (first) {
                         // row 0: linear starts from "one deletion before column 0" so that cell j costs j
                         // deletions; affine makes the diagonal candidate of cell (0,0) cost exactly 0
-                        if constexpr (AFF) diag = (uint32_t)fc.diag0; else left = (uint32_t)(-(fc.del + (QV ? 128 : 0)) * 32);
+                        if constexpr (AFF) diag = (uint32_t)fc.diag0;
+                        else if constexpr (!LOCAL) left = (uint32_t)(-(fc.del + (QV ? 128 : 0)) * 32);
                     }
                     first = false;
                 }
@@ -949,7 +966,12 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                             if constexpr (QV) l = (int32_t)((__builtin_amdgcn_perm(dhi, dlo, tcd) << SH) + left) + codeL8;
                             else l = (int32_t)left + fc.cL;
                             if constexpr (!AFF) {
-                                const uint32_t best = (uint32_t)min(m, min(u, l));
+                                uint32_t best = (uint32_t)min(m, min(u, l));
+                                if constexpr (LOCAL) {
+                                    best = (uint32_t)min((int32_t)best, startw);
+                                    const int32_t key = (int32_t)((best & ~TAGS) | (uint32_t)k);
+                                    stepmin = min(stepmin, (uint32_t)k < rem ? key : 0x7fffffff);
+                                }
                                 const uint32_t cw = (u_ & TAGS) | (best & ~TAGS);
                                 wr[k * 64] = cw;
                                 // arrow = bits 3..4 of best -> record bits 2k..2k+1: a field extract and a shift-or with
@@ -1011,6 +1033,11 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                     *(u32x3u *)(recb + rob) = u32x3u{ar[0], one ? meta : ar[1], meta};
                     rob += k0 >= W && rem > 16u ? 12u : 8u;
                 }
+                if constexpr (LOCAL) {
+                    const int32_t sc = (int32_t)((uint32_t)stepmin & ~TAGS) - (int32_t)(rrow * 4096u);
+                    if (stepmin != 0x7fffffff && sc < bsc) { bsc = sc; bi = rrow; bj = lo_abs + (k0 - (uint32_t)CAP) + ((uint32_t)stepmin & TAGS); blo = lo_abs; fresh = true; }
+                    if (k0 >= W && fresh) { bptr = (rob - 4u - rob0) >> 2; fresh = false; }      // the row's meta dword is the last one stored
+                }
                 if (k0 >= W) {
                     if constexpr (AFF) {
                         *(uint32_t *)(recb + rob) = meta;
@@ -1037,6 +1064,14 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
             const uint32_t *src = st + ws;
             S0 = *(const u32x4 *)(src); S1 = *(const u32x4 *)(src + 4); S2 = *(const u32x4 *)(src + 8); S3 = *(const u32x4 *)(src + 12);
         }
+    }
+    if constexpr (LOCAL) {
+        if (live) {
+            if (!finished) d.status[p] = GBA_PAIR_UNREACHABLE;
+            else if (bsc >= 0) { d.status[p] = GBA_PAIR_NO_ALIGNMENT; d.dp_score[p] = 0; }
+            else { d.end_i[p] = bi; d.end_j[p] = bj; d.end_lo[p] = blo; d.end_ptr[p] = bptr; d.dp_score[p] = bsc >> SH; }
+        }
+        return;
     }
     if (live) {
         const int32_t v = (int32_t)(final_word & ~TAGS) - (int32_t)(QV ? d.T[p] : Q) * (128 << SH);
@@ -1758,9 +1793,12 @@ constexpr int TB_LANES = GBA_TB_LANES;      // pairs per wave: the walk is a dep
 // RW: record dwords per lane in the window.  An affine row of 33 cells is ten dwords, so 64 dwords are five rows between
 // refills and a walk of few pairs (one wave per CU or two, nothing to hide the refill behind) spends half its time on
 // them; such launches take 192 dwords (TB_RW_FEW), which at 52 KB of LDS a wave is no way to run a full batch.
-template <bool AFF, int RW = TB_RW>
+// LOCAL (linear gaps): the walk begins in the cell the fill left in Dev::end_* and ends at the first cell that carries the
+// arrow code 3 ("the alignment begins behind this cell"); gap bases are counted inside the aligned stretch only.
+template <bool AFF, int RW = TB_RW, bool LOCAL = false>
 __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_pair_result *res, uint32_t first, uint32_t count)
 {
+    static_assert(!LOCAL || !AFF, "the Local end rule: linear gaps");
     __shared__ int32_t sub[25 * (1 + GBA_MAX_EXTRA)];     // the stats scorer's matrix, then the extra scorers'
     __shared__ uint32_t rwin[RW * TB_LANES];
     __shared__ uint32_t twin[TB_TW * TB_LANES];
@@ -1781,7 +1819,9 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
     const uint8_t *twin8 = (const uint8_t *)twin;
     constexpr uint32_t CSHIFT = AFF ? 2u : 4u, CMASK = AFF ? 3u : 15u, BITS = AFF ? 8u : 2u;
     BlkOut bo = blk_out_begin(d, p);
-    uint32_t i = Q, j = T, lo = d.lo_last[p], nb = 0, run = 0;
+    uint32_t i = LOCAL ? d.end_i[p] : Q, j = LOCAL ? d.end_j[p] : T, lo = LOCAL ? d.end_lo[p] : d.lo_last[p], nb = 0, run = 0;
+    const uint32_t ei = i, ej = j;
+    bool done = false;                            // LOCAL: the walk has come to the cell the alignment begins behind
     uint32_t nM = 0, ndiag = 0, nopen = 0;
     int32_t score = 0;
     uint32_t prev_op = 0;
@@ -1790,7 +1830,7 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
     // affine paths spend an extra step on every gap-state change
     uint32_t budget = (Q + T + 2u) * (AFF ? 3u : 1u);
     bool ok = true;
-    int32_t ptr = (int32_t)d.recdw[p] - 1;        // meta dword of the current row
+    int32_t ptr = LOCAL ? (int32_t)d.end_ptr[p] : (int32_t)d.recdw[p] - 1;        // meta dword of the current row
     int32_t rb = 0x40000000, tb = 0x40000000;     // first record dword / code dword held in the windows
     uint32_t gw = live ? rec[ptr] : 0u;
     uint32_t W = gw & ROW_W_MASK, n = (W + CMASK) >> CSHIFT;   // width, arrow dwords of the current row
@@ -1802,7 +1842,7 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
         mvtab |= (a == tc_.codeU ? 1u : a == tc_.codeL ? 2u : (AFF && a <= 4u) ? 3u : 4u) << (4u * a);
     constexpr uint32_t S0TAB = (2u << 12) | (1u << 16);
     for (;;) {
-        const bool active = live && ok && (i | j) != 0u;
+        const bool active = live && ok && (i | j) != 0u && !(LOCAL && done);
         if (!__any(active)) break;
         {
             // linear pairs of the lane classes have rows of at most 8 arrow dwords: always inside the window
@@ -1856,6 +1896,7 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
             uint32_t mv;
             if constexpr (!AFF) {
                 mv = (mvtab >> ((cell & 3u) * 4u)) & 7u;
+                if constexpr (LOCAL) { if (inband && (cell & 3u) == 3u) { mv = 3u; done = true; } }      // no move, and the walk is over
             } else {
                 const uint32_t a4 = ((cell >> 3) & 7u) * 4u;
                 const uint32_t m0 = (mvtab >> a4) & 7u;
@@ -1905,7 +1946,7 @@ __global__ __launch_bounds__(TB_LANES) void k_traceback(Dev d, TbConst tc_, gba_
     d.blk_end[p] = bo.end;
     if (!ok) { d.status[p] = GBA_PAIR_UNREACHABLE; return; }
     // every row is consumed by a diagonal or an up move, every column by a diagonal or a left move
-    const uint32_t nI = Q - ndiag, nD = T - ndiag;
+    const uint32_t nI = (LOCAL ? ei - i : Q) - ndiag, nD = (LOCAL ? ej - j : T) - ndiag;
     score += gap_score(tc_.affine, tc_.ins, tc_.del, tc_.aopen, tc_.aext, nI, nD, nopen);
     R.n_blk = nb; R.score = score;
     d.span[p] = bo.room ? nb : 0u;            // no room: nothing of this pair is read, the batch is run again
@@ -3009,12 +3050,14 @@ int launch_fill(gba_ctx *c, const Dev &d, uint32_t cls, uint32_t count, hipStrea
         HIPCHK(c, hipFuncSetAttribute((const void *)k_fill<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(c, hipFuncSetAttribute((const void *)(k_fill<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(c, hipFuncSetAttribute((const void *)(k_fill<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(c, hipFuncSetAttribute((const void *)(k_fill<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         c->lds_attr_set = true;
     }
     const dim3 grid((count + 63) / 64), block(64);
     if (aff && d.prof) hipLaunchKernelGGL((k_fill<true, true>), grid, block, lds, st, d, c->fc, cls, slots);
     else if (aff) hipLaunchKernelGGL(k_fill<true>, grid, block, lds, st, d, c->fc, cls, slots);
     else if (d.prof) hipLaunchKernelGGL((k_fill<false, true>), grid, block, lds, st, d, c->fc, cls, slots);
+    else if (c->sc.align_type == GBA_ALIGN_LOCAL) hipLaunchKernelGGL((k_fill<false, false, true>), grid, block, lds, st, d, c->fc, cls, slots);
     else hipLaunchKernelGGL(k_fill<false>, grid, block, lds, st, d, c->fc, cls, slots);
     HIPCHK(c, hipGetLastError());
     return GBA_OK;
@@ -3078,11 +3121,11 @@ int phase_guide(gba_ctx *c, Slot &sl, Dev &d)
     // times the instructions per cell but fill the GPU from a few thousand pairs on.  Below wave_pairs
     // pairs the whole batch runs one wave per pair.
     const bool affine = sc.mode == GBA_MODE_AFFINE;
-    const bool local = sc.align_type == GBA_ALIGN_LOCAL;      // the free-start / best-cell end rule lives in the wave-per-pair kernels
+    const bool local = sc.align_type == GBA_ALIGN_LOCAL;
     // (affine gaps with a cost profile: the wave-per-pair kernel composes a min-plus map per column, and the lane classes win from
     // about 24 000 pairs of 10 kb on: 32 768 pairs 146 against 91 GCUPS, 16 384 pairs 76 against 83)
     const uint32_t lanes_from = affine ? (d.prof ? c->wave_pairs_affine_prof : c->wave_pairs_affine) : c->wave_pairs;
-    const int lane_classes = local || d.n < lanes_from ? 0
+    const int lane_classes = (local && d.prof) || d.n < lanes_from ? 0        // the Local end rule with a cost profile: the wave-per-pair kernels have it
                            : affine ? (top_lane_slots(c, d) ? LANE_CLS_AFFINE + 1 : LANE_CLS_AFFINE) : LANE_CLS_LINEAR;
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(SCAN_T), 0, sl.s, d, lane_classes, 1, top_lane_slots(c, d));
     HIPCHK(c, hipGetLastError());
@@ -3122,7 +3165,8 @@ int phase_fill(gba_ctx *c, Slot &sl, Dev &d, gba_pair_result *res, uint32_t max_
     auto launch_tb_lanes = [&](hipStream_t st) {
         const uint32_t cnt = pl.cls_base[CLS_WIDE];
         const dim3 grid((cnt + TB_LANES - 1) / TB_LANES), block(TB_LANES);
-        if (aff && cnt <= c->tb_few_max) hipLaunchKernelGGL((k_traceback<true, TB_RW_FEW>), grid, block, 0, st, d, c->tbc, res, 0u, cnt);
+        if (local) hipLaunchKernelGGL((k_traceback<false, TB_RW, true>), grid, block, 0, st, d, c->tbc, res, 0u, cnt);
+        else if (aff && cnt <= c->tb_few_max) hipLaunchKernelGGL((k_traceback<true, TB_RW_FEW>), grid, block, 0, st, d, c->tbc, res, 0u, cnt);
         else if (aff) hipLaunchKernelGGL(k_traceback<true>, grid, block, 0, st, d, c->tbc, res, 0u, cnt);
         else hipLaunchKernelGGL(k_traceback<false>, grid, block, 0, st, d, c->tbc, res, 0u, cnt);
     };

@@ -82,10 +82,14 @@ def test_local_hand_cases(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("family", ["lane-per-pair", "wave-per-pair"])
 @pytest.mark.parametrize("band,tie", [(12, 0), (12, 1), (90, 0)])
-def test_local_rule_on_the_device(oracle, band, tie):
+def test_local_rule_on_the_device(oracle, monkeypatch, band, tie, family):
     """Reads whose ends do not align (unrelated sequence in front of and behind a common core, inside the DP region), pairs
-    that align end to end and pairs in which nothing aligns; narrow and wide bands; host and device batches."""
+    that align end to end and pairs in which nothing aligns; narrow and wide bands; host and device batches; on the lane
+    classes (k_fill<false, false, true>, the lane-per-pair traceback from the cheapest cell; band 90: the pairs narrow
+    enough for a lane class) and one wave per pair."""
+    monkeypatch.setenv("GBA_WAVE_PAIRS", "1" if family == "lane-per-pair" else "4000000000")
     import torch
     from blasr_amd import api, _lib
     rng = np.random.default_rng(40 + band + tie)
@@ -110,11 +114,13 @@ def test_local_rule_on_the_device(oracle, band, tie):
     batch = {"n_pairs": n, "q_arena": np.frombuffer(b"".join(c[0] for c in cases), np.uint8), "t_arena": np.frombuffer(b"".join(c[1] for c in cases), np.uint8),
              "blocks": blk, "q_off": off(q_len), "t_off": off(t_len), "blk_off": off(n_blk), "q_len": q_len, "t_len": t_len, "n_blk": n_blk}
     kw = dict(band=band, tie_break=tie)
-    ctx = api.Context(0)
+    ctx = api.Context(0, timing=True)
     try:
         ctx.set_scoring(api.make_scoring(align_type=_lib.ALIGN_LOCAL, **kw))
         pairs, blocks, rc = ctx.refine_host(batch)
         assert rc == 0
+        wide = int(ctx.timing()["wide_pairs"])
+        assert wide >= n - 6 if family == "wave-per-pair" else (wide < n // 2 if band == 12 else wide <= n), wide
         OP = oracle.make_params(align_type=oracle.ALIGN_LOCAL, **kw)
         trimmed = empty = 0
         for p, (q, t, b) in enumerate(cases):
