@@ -250,12 +250,12 @@ def kernel_name(cfg, tm, n, quad_min, qv=False):
     if qv:
         if tm["wide_pairs"] * 2 > n:
             return "k_fill_wide_affine<.., true>" if affine else "k_fill_wide<.., true>"
-        return "k_fill<false, true>"
+        return "k_fill<false, true, false>"
     if tm["wide_pairs"] * 2 > n:               # most pairs ran wave-per-pair
         if affine:
             return "k_fill_quad_affine" if tm["wide_pairs"] >= quad_min and cfg["band"] <= 30 else "k_fill_wide_affine"
         return "k_fill_wide_cols" if cfg["band"] > 30 else "k_fill_wide<1>"
-    return "k_fill<%s, false>" % ("true" if affine else "false")
+    return "k_fill<%s, false, false>" % ("true" if affine else "false")
 
 
 def stream_batches(torch, pipe, dbatch, bufs, warm, count):

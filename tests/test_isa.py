@@ -13,8 +13,8 @@ import pytest
 
 from blasr_amd import build
 
-KERNELS = {"k_fill<false>": "_ZN12_GLOBAL__N_16k_fillILb0ELb0EEEvNS_3DevENS_9FillConstEjj",
-           "k_fill<true>": "_ZN12_GLOBAL__N_16k_fillILb1ELb0EEEvNS_3DevENS_9FillConstEjj"}
+KERNELS = {"k_fill<false>": "_ZN12_GLOBAL__N_16k_fillILb0ELb0ELb0EEEvNS_3DevENS_9FillConstEjj",
+           "k_fill<true>": "_ZN12_GLOBAL__N_16k_fillILb1ELb0ELb0EEEvNS_3DevENS_9FillConstEjj"}
 
 
 def _regs(tok):
