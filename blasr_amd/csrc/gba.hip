@@ -786,16 +786,18 @@ __device__ __forceinline__ uint32_t qv_bytes(uint32_t two)       // two int16 co
 }
 
 //
-// LOCAL (linear gaps, matrix costs; gba_scoring.align_type GBA_ALIGN_LOCAL as in k_fill_wide): every cell may begin an
+// LOCAL (linear gaps; gba_scoring.align_type GBA_ALIGN_LOCAL as in k_fill_wide): every cell may begin an
 // alignment (a fourth candidate of score 0 with the arrow code 3, last in the tie-break), row 0 has no deletion chain,
 // and the lane keeps the cheapest cell of its pair, the first in row-major order among equals: per step the minimum of
 // score | cell number over the step's cells OF THE ROW (the groups run past a row's end, and what they compute there may
 // be a real cell outside the band), compared with the best so far once the row bias is taken off.  The cell's row,
-// column, first column of its row and the meta dword of that row go to Dev::end_* for the traceback.
+// column, first column of its row and the meta dword of that row go to Dev::end_* for the traceback.  With a cost profile
+// (QV: the CCS call site runs the rule with the quality-value scorer) the bias is 128 x the cell's column, so the start
+// candidate and the key are made per cell, relative to the step's first column.
 template <bool AFF, bool QV = false, bool LOCAL = false>
 __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, uint32_t slots)
 {
-    static_assert(!LOCAL || (!AFF && !QV), "the Local end rule: linear gaps, matrix costs");
+    static_assert(!LOCAL || !AFF, "the Local end rule: linear gaps");
     extern __shared__ uint32_t smem[];
     // Claims 200 of a SIMD's 512 VGPRs per wave, so that at most two fill waves (of any class) share
     // a SIMD and a wave of another kernel still fits beside them.  LDS would admit a third fill wave
@@ -921,6 +923,7 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
     #pragma unroll
             for (int x = 0; x < NAR; x++) ar[x] = 0;
             int32_t stepmin = 0x7fffffff;               // LOCAL: cheapest cell of the row in this step, score | cell number within the step
+            const int32_t sbase = (int32_t)((lo_abs + k0) * 4096u) + (3 << 3);      // LOCAL with QV: the start candidate of the step's first cell
             // One LDS round trip for everything the step's first cells need: the diagonal predecessor of
             // a new row's first cell and the vertical predecessors of the first 8 cells (lanes without
             // cells this step read slots 0..7, which always exist).
@@ -937,7 +940,7 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                         // row 0: linear starts from "one deletion before column 0" so that cell j costs j
                         // deletions; affine makes the diagonal candidate of cell (0,0) cost exactly 0
                         if constexpr (AFF) diag = (uint32_t)fc.diag0;
-                        else if constexpr (!LOCAL) left = (uint32_t)(-(fc.del + (QV ? 128 : 0)) * 32);
+                        else if constexpr (!LOCAL) left = (uint32_t)(-(fc.del + (QV ? 128 : 0)) * 32);       // (LOCAL: row 0 has no deletion chain)
                     }
                     first = false;
                 }
@@ -968,8 +971,9 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                             if constexpr (!AFF) {
                                 uint32_t best = (uint32_t)min(m, min(u, l));
                                 if constexpr (LOCAL) {
-                                    best = (uint32_t)min((int32_t)best, startw);
-                                    const int32_t key = (int32_t)((best & ~TAGS) | (uint32_t)k);
+                                    // QV: sbase carries the bias of the step's first column, cell k has k x 4096 more
+                                    best = (uint32_t)min((int32_t)best, QV ? sbase + k * 4096 : startw);
+                                    const int32_t key = (int32_t)((best & ~TAGS) | (uint32_t)k) - (QV ? k * 4096 : 0);
                                     stepmin = min(stepmin, (uint32_t)k < rem ? key : 0x7fffffff);
                                 }
                                 const uint32_t cw = (u_ & TAGS) | (best & ~TAGS);
@@ -1034,7 +1038,7 @@ __global__ __launch_bounds__(64) void k_fill(Dev d, FillConst fc, uint32_t cls, 
                     rob += k0 >= W && rem > 16u ? 12u : 8u;
                 }
                 if constexpr (LOCAL) {
-                    const int32_t sc = (int32_t)((uint32_t)stepmin & ~TAGS) - (int32_t)(rrow * 4096u);
+                    const int32_t sc = (int32_t)((uint32_t)stepmin & ~TAGS) - (int32_t)((QV ? lo_abs + (k0 - (uint32_t)CAP) : rrow) * 4096u);
                     if (stepmin != 0x7fffffff && sc < bsc) { bsc = sc; bi = rrow; bj = lo_abs + (k0 - (uint32_t)CAP) + ((uint32_t)stepmin & TAGS); blo = lo_abs; fresh = true; }
                     if (k0 >= W && fresh) { bptr = (rob - 4u - rob0) >> 2; fresh = false; }      // the row's meta dword is the last one stored
                 }
@@ -3051,11 +3055,13 @@ int launch_fill(gba_ctx *c, const Dev &d, uint32_t cls, uint32_t count, hipStrea
         HIPCHK(c, hipFuncSetAttribute((const void *)(k_fill<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(c, hipFuncSetAttribute((const void *)(k_fill<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(c, hipFuncSetAttribute((const void *)(k_fill<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(c, hipFuncSetAttribute((const void *)(k_fill<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         c->lds_attr_set = true;
     }
     const dim3 grid((count + 63) / 64), block(64);
     if (aff && d.prof) hipLaunchKernelGGL((k_fill<true, true>), grid, block, lds, st, d, c->fc, cls, slots);
     else if (aff) hipLaunchKernelGGL(k_fill<true>, grid, block, lds, st, d, c->fc, cls, slots);
+    else if (d.prof && c->sc.align_type == GBA_ALIGN_LOCAL) hipLaunchKernelGGL((k_fill<false, true, true>), grid, block, lds, st, d, c->fc, cls, slots);
     else if (d.prof) hipLaunchKernelGGL((k_fill<false, true>), grid, block, lds, st, d, c->fc, cls, slots);
     else if (c->sc.align_type == GBA_ALIGN_LOCAL) hipLaunchKernelGGL((k_fill<false, false, true>), grid, block, lds, st, d, c->fc, cls, slots);
     else hipLaunchKernelGGL(k_fill<false>, grid, block, lds, st, d, c->fc, cls, slots);
@@ -3121,11 +3127,10 @@ int phase_guide(gba_ctx *c, Slot &sl, Dev &d)
     // times the instructions per cell but fill the GPU from a few thousand pairs on.  Below wave_pairs
     // pairs the whole batch runs one wave per pair.
     const bool affine = sc.mode == GBA_MODE_AFFINE;
-    const bool local = sc.align_type == GBA_ALIGN_LOCAL;
     // (affine gaps with a cost profile: the wave-per-pair kernel composes a min-plus map per column, and the lane classes win from
     // about 24 000 pairs of 10 kb on: 32 768 pairs 146 against 91 GCUPS, 16 384 pairs 76 against 83)
     const uint32_t lanes_from = affine ? (d.prof ? c->wave_pairs_affine_prof : c->wave_pairs_affine) : c->wave_pairs;
-    const int lane_classes = (local && d.prof) || d.n < lanes_from ? 0        // the Local end rule with a cost profile: the wave-per-pair kernels have it
+    const int lane_classes = d.n < lanes_from ? 0
                            : affine ? (top_lane_slots(c, d) ? LANE_CLS_AFFINE + 1 : LANE_CLS_AFFINE) : LANE_CLS_LINEAR;
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(SCAN_T), 0, sl.s, d, lane_classes, 1, top_lane_slots(c, d));
     HIPCHK(c, hipGetLastError());

@@ -200,9 +200,13 @@ def check_kband(rng, api, oracle, _lib, ctx, pool, batch):
     return None, kw
 
 
-def check_qv(rng, api, oracle, _lib, ctx, pool, batch, kw):
+def check_qv(rng, api, oracle, _lib, ctx, pool, batch, kw, local=False):
     """The round's batch again with the costs of a quality-value scorer (gba_batch.q_profile, random values, some outside
-    +-127, or +-63 with affine gaps) against gbo_align_qv: linear and affine gaps, the k-band geometry."""
+    +-127, or +-63 with affine gaps) against gbo_align_qv: linear and affine gaps, the k-band geometry; local: under the
+    Local end rule (the CCS call site's combination)."""
+    if local:
+        kw = dict(kw, align_type=_lib.ALIGN_LOCAL)
+        ctx.set_scoring(api.make_scoring(**kw))
     n = int(batch["n_pairs"])
     na = len(batch["q_arena"])
     prof = rng.integers(-20, 60, (na, 11)).astype(np.int16)
@@ -414,6 +418,8 @@ def main():
             packed_rounds += 1
         if not bad and rounds % 5 == 1 and kw["mode"] == _lib.MODE_LINEAR:
             bad = check_local(api, oracle, _lib, ctx, pool, batch, kw)
+            if not bad and rounds % 10 == 1:
+                bad = check_qv(rng, api, oracle, _lib, ctx, pool, batch, kw, local=True)
             local_rounds += 1
         rounds += 1; pairs_done += n
         for v, c in zip(*np.unique(pairs["status"], return_counts=True)):

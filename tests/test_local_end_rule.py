@@ -162,9 +162,12 @@ def test_local_rule_on_the_device(oracle, monkeypatch, band, tie, family):
 
 
 @pytest.mark.gpu
-def test_local_rule_with_a_cost_profile(oracle):
-    """The CCS call site runs the Local rule with the IDS scorer: a per-base cost profile through the same kernels."""
+@pytest.mark.parametrize("family", ["lane-per-pair", "wave-per-pair"])
+def test_local_rule_with_a_cost_profile(oracle, monkeypatch, family):
+    """The CCS call site runs the Local rule with the IDS scorer: a per-base cost profile through the same kernels, one
+    lane per pair (k_fill<false, true, true>) and one wave per pair."""
     from blasr_amd import api, _lib
+    monkeypatch.setenv("GBA_WAVE_PAIRS", "1" if family == "lane-per-pair" else "4000000000")
     rng = np.random.default_rng(77)
     cases = [_case(rng, int(rng.integers(200, 700)), (int(rng.integers(4, 80)), int(rng.integers(4, 80))),
                    (int(rng.integers(4, 80)), int(rng.integers(4, 80)))) for _ in range(24)]
@@ -184,11 +187,13 @@ def test_local_rule_with_a_cost_profile(oracle):
     prof = prof.reshape(-1)
     batch = {"n_pairs": n, "q_arena": qa, "t_arena": np.frombuffer(b"".join(c[1] for c in cases), np.uint8), "blocks": blk,
              "q_off": off(q_len), "t_off": off(t_len), "blk_off": off(n_blk), "q_len": q_len, "t_len": t_len, "n_blk": n_blk, "q_profile": prof}
-    ctx = api.Context(0)
+    ctx = api.Context(0, timing=True)
     try:
         ctx.set_scoring(api.make_scoring(align_type=_lib.ALIGN_LOCAL, band=12))
         pairs, blocks, rc = ctx.refine_host(batch)
         assert rc == 0
+        wide = int(ctx.timing()["wide_pairs"])
+        assert wide == n if family == "wave-per-pair" else wide < n // 2, wide
         OP = oracle.make_params(align_type=oracle.ALIGN_LOCAL, band=12)
         for p, (q, t, b) in enumerate(cases):
             o = int(batch["q_off"][p])
