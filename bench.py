@@ -244,13 +244,13 @@ def launch_ranks(n_gpus):
     return subprocess.call(cmd)
 
 
-def kernel_name(cfg, tm, n, quad_min, qv=False):
+def kernel_name(cfg, tm, n, quad_min, qv=False, local=False):
     """The fill kernel that ran the bulk of a batch, from the library's own routing."""
     affine = cfg["mode"] == "affine"
-    if qv:
+    if qv or local:
         if tm["wide_pairs"] * 2 > n:
-            return "k_fill_wide_affine<.., true>" if affine else "k_fill_wide<.., true>"
-        return "k_fill<false, true, false>"
+            return "k_fill_wide_affine<.., %s>" % str(qv).lower() if affine else "k_fill_wide<.., %s, %s>" % (str(qv).lower(), str(local).lower())
+        return "k_fill<%s, %s, %s>" % (str(affine).lower(), str(qv).lower(), str(local).lower())
     if tm["wide_pairs"] * 2 > n:               # most pairs ran wave-per-pair
         if affine:
             return "k_fill_quad_affine" if tm["wide_pairs"] >= quad_min and cfg["band"] <= 30 else "k_fill_wide_affine"
@@ -277,7 +277,7 @@ def stream_batches(torch, pipe, dbatch, bufs, warm, count):
     return dt / count, int(rc)
 
 
-def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None, stream_depth=0, qv=False):
+def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None, stream_depth=0, qv=False, local=False):
     """One of the other BASELINE configurations, device-resident like the headline: generate, one warm-up step, `steps`
     timed steps; the same definitions of GCUPS and of the fill's share of the int32 VALU peak.  stream_depth: also the
     rate of a caller that streams such batches through that many contexts, a worker thread each (the reference's worker
@@ -311,7 +311,9 @@ def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None,
     out_pairs = torch.zeros(n * _lib.PAIR_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda:0")
     out_blocks = torch.zeros((cap, 3), dtype=torch.int32, device="cuda:0")
     ctx = api.Context(0, timing=True)
-    ctx.set_scoring(api.make_scoring(band=cfg["band"], max_band=max_band, mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR))
+    # local: the Local end rule of the CCS call site (/root/reference/iblasr/BlasrAlignImpl.hpp:1418-1421) on the same pairs
+    ctx.set_scoring(api.make_scoring(band=cfg["band"], max_band=max_band, mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR,
+                                     align_type=_lib.ALIGN_LOCAL if local else _lib.ALIGN_GLOBAL))
     rc, _ = ctx.refine_device(d, out_pairs, out_blocks)
     torch.cuda.synchronize()
     fill = tb = 0.0
@@ -328,7 +330,7 @@ def other_workload(torch, api, synth, _lib, name, n, steps, max_band, band=None,
     ops = OPS_PER_CELL[cfg["mode"]]
     r = {"pairs": n, "read_len": cfg["read_len"], "band": cfg["band"], "gaps": cfg["mode"], "candidates_per_read": k, "rc": rc,
          "pairs_ok": int((res["status"] == 0).sum()), "ms_per_step": round(dt * 1e3, 3), "gcups": round(cells / dt / 1e9, 2),
-         "kernel": kernel_name(cfg, tm, n, int(os.environ.get("GBA_QUAD_AFFINE_MIN", "10240")), qv),
+         "kernel": kernel_name(cfg, tm, n, int(os.environ.get("GBA_QUAD_AFFINE_MIN", "10240")), qv, local),
          "fill_ms": round(fill_s * 1e3, 3), "traceback_ms": round(tb / steps, 3), "fill_gcups": round(cells / fill_s / 1e9, 2),
          "frac": round(cells * ops / fill_s / 1e12 / VALU_PEAK_TOPS, 4), "steps": steps}
     if stream_depth > 1:
@@ -669,12 +671,13 @@ def main():
         out["other_workloads"] = {}
         for key, name, pairs, band in (("c3_20kb_affine", "c3_20kb_affine", 16384, None), ("c5_50kb_band100", "c5_50kb_wide", 2048, 100),
                                        ("c4_chr20_bestn10", "c4_chr20_bestn10", 163840, None),
-                                       ("c2_10kb_quality_values", "c2_10kb_linear", 122880, None)):
+                                       ("c2_10kb_quality_values", "c2_10kb_linear", 122880, None),
+                                       ("c2_10kb_local_end_rule", "c2_10kb_linear", 122880, None)):
             try:
                 # (C4 is two parts, which overlap inside one context already: 2 % from a second one, not measured here)
                 out["other_workloads"][key] = other_workload(torch, api, synth, _lib, name, pairs, 2, args.max_band, band,
                                                              stream_depth=4 if key in ("c3_20kb_affine", "c5_50kb_band100") else 0,
-                                                             qv=key == "c2_10kb_quality_values")
+                                                             qv=key == "c2_10kb_quality_values", local=key == "c2_10kb_local_end_rule")
             except Exception as e:          # a failure here must not cost the headline line
                 out["other_workloads"][key] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_end_to_end and args.workload == "c2_10kb_linear":
