@@ -47,6 +47,10 @@ sys.path.insert(0, ROOT)
 # HBM bytes of one step's fill launches at the default workload, from separate rocprofv3 --pmc passes of
 # this command (profiles/, WRITE_SIZE + 2 x FETCH_SIZE: the gfx950 correction for streamed reads)
 MEASURED_FILL_TRAFFIC = {("c2_10kb_linear", 491520): 125906804 * 1024 + 2 * 18229433 * 1024}
+# The host legs (host to host, end to end) run in processes of their own BEFORE this process touches the GPU: an idle HIP
+# context beside them (its hardware queues stay allocated) costs them a third of their rate (host to host 472 against
+# 651 GCUPS, to intervals 569 against 844 on the same box).
+HOST_HW_QUEUES = os.environ.get("GBA_BENCH_HOST_HW_QUEUES", "16")
 OPS_PER_CELL = {"linear": 8, "affine": 18}         # algorithmic int32 ops per DP cell
 BYTES_PER_CELL = {"linear": 0.25, "affine": 0.75}  # algorithmic traceback bytes per cell
 VALU_PEAK_TOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz int32 lane-ops/s (= half the 157.3 TFLOP/s fp32 vector peak)
@@ -106,9 +110,11 @@ def host_child(args):
     pipe = api.HostPipeline(0, depth=args.host_contexts, stagger=float(os.environ.get("BENCH_STAGGER", "0.4")))
     pipe.set_scoring(api.make_scoring(band=cfg["band"], max_band=args.max_band, mode=_lib.MODE_AFFINE if affine else _lib.MODE_LINEAR))
     pipe.set_reference(ref)
+    # room for the refined blocks: what the caller says the batch needs plus a twelfth, else a block per four bases
+    cap_blocks = args.host_blocks + args.host_blocks // 12 if args.host_blocks else int(host["q_len"].astype(np.int64).sum() // 4) + n
     bufs = []
     for _ in range(args.host_contexts):
-        bufs.append((pipe.pinned_copy(host), pipe.host_array(n, _lib.PAIR_RESULT_DT), pipe.host_array(args.host_blocks + args.host_blocks // 12, _lib.BLOCK_DT)))
+        bufs.append((pipe.pinned_copy(host), pipe.host_array(n, _lib.PAIR_RESULT_DT), pipe.host_array(cap_blocks, _lib.BLOCK_DT)))
     for i in range(args.host_contexts):           # warm-up: every context once (its device buffers grow to size)
         pipe.submit(*bufs[i]); rc, needed = pipe.wait()
         if rc != 0:
@@ -222,6 +228,38 @@ def fixed_band(api, _lib, host, n, threads):
         secs = time.perf_counter() - t1
         r["cpu_baseline"] = {"extensions_per_sec": round(done / secs, 1), "gcups": round(cells / secs / 1e9, 3), "cores": threads, "kind": "port",
                              "same_results": same, "sample": "%d pairs in %.1f s (oracle/kband_oracle.c through ctypes, %d threads)" % (done, secs, threads)}
+    return r
+
+
+def host_legs_first(args):
+    """The legs that run in processes of their own -- the host-to-host child and the read-level harness -- before this
+    process has touched the GPU; what they printed is folded into the line later.  A HIP context that sits idle beside
+    them keeps its hardware queues, and the two contexts of a host pipeline then share what is left."""
+    import subprocess
+    from blasr_amd import synth
+    r = {}
+    if not args.no_host:
+        k = dict(synth.PRESETS[args.workload]).get("decoy_every", 0) or 1
+        n = args.pairs if args.pairs is not None else DEFAULT_PAIRS[args.workload]
+        n -= n % k
+        env = dict(os.environ, GBA_NO_TORCH="1", GPU_MAX_HW_QUEUES=HOST_HW_QUEUES)
+        cmd = [sys.executable, os.path.abspath(__file__), "--host-child", "--workload", args.workload, "--pairs", str(n),
+               "--max-band", str(args.max_band), "--host-steps", str(args.host_steps), "--host-contexts", str(args.host_contexts),
+               "--host-blocks", "0"] + (["--band", str(args.band)] if args.band is not None else [])
+        r["host_child"] = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    if not args.no_end_to_end and args.workload == "c2_10kb_linear":
+        from blasr_amd import build
+        e = {"what": "read_harness: candidates from the generator -> gba_submit from sequences (guides made on the device, refine, "
+                     "pair results only) -> per read sort / filters / mapQV / m4 text; two contexts in turn, 4 batches back to back"}
+        env = dict(os.environ, GPU_MAX_HW_QUEUES=HOST_HW_QUEUES)
+        for key, argv in (("c2_10kb_1_candidate", ["--reads", "122880", "--cands", "1", "--read-len", "10000", "--ref-len", str(synth.ECOLI_LEN), "--n-frac", "0", "--seed", "2000"]),
+                          ("c4_chr20_10_candidates", ["--reads", "16384", "--cands", "10", "--read-len", "10000", "--ref-len", str(synth.CHR20_LEN), "--n-frac", "0.01", "--seed", "4000"])):
+            try:
+                p = subprocess.run([build.READ_HARNESS] + argv + ["--batches", "4"], env=env, capture_output=True, text=True, timeout=600)
+                e[key] = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else {"error": (p.stderr or p.stdout)[-300:]}
+            except Exception as x:
+                e[key] = {"error": repr(x)[:300]}
+        r["end_to_end"] = e
     return r
 
 
@@ -381,6 +419,8 @@ def main():
         raise SystemExit("--gpus must be at least 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus))
+
+    early = host_legs_first(args) if int(os.environ.get("WORLD_SIZE", "1")) == 1 else {}
 
     import torch
     from blasr_amd import api, shard, synth, _lib
@@ -603,18 +643,13 @@ def main():
         torch.cuda.synchronize()
 
     if rank == 0 and world == 1 and not args.no_host:
-        # The same batch from host memory to host memory (gba_submit / gba_wait), measured by a child
-        # process: see host_child().  This process gives the GPU's memory back first.
-        import subprocess
+        # The same batch from host memory to host memory (gba_submit / gba_wait), measured by a child process before this
+        # one touched the GPU: see host_child() and host_legs_first().
         digest = results_digest(res, out_blocks[:needed_dev[0]].cpu().numpy())
         del dbatch, out_blocks, out_pairs
         ctx.close()
         torch.cuda.empty_cache()
-        env = dict(os.environ, GBA_NO_TORCH="1", GPU_MAX_HW_QUEUES="16")
-        cmd = [sys.executable, os.path.abspath(__file__), "--host-child", "--workload", args.workload, "--pairs", str(n),
-               "--max-band", str(args.max_band), "--host-steps", str(args.host_steps), "--host-contexts", str(args.host_contexts),
-               "--host-blocks", str(needed_dev[0] + 16)] + (["--band", str(args.band)] if args.band is not None else [])
-        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        p = early["host_child"]
         if p.returncode != 0:
             out["host_to_host"] = {"error": (p.stderr or p.stdout)[-400:]}
         else:
@@ -642,7 +677,7 @@ def main():
                                           for k, v in h["from_sequences"].items()}},
                                    "how": "gba_submit / gba_wait, batch and results in page-locked memory (gba_host_alloc), targets = windows of "
                                           "the resident reference, %d contexts used in turn on the GPU, %d batches back to back, "
-                                          "GPU_MAX_HW_QUEUES=16, child process on the system HIP runtime" % (args.host_contexts, args.host_steps)}
+                                          "GPU_MAX_HW_QUEUES=%s, child process on the system HIP runtime" % (args.host_contexts, args.host_steps, HOST_HW_QUEUES)}
 
     if rank == 0 and world == 1 and not args.no_cpu:
         threads = host_cores()
@@ -685,18 +720,7 @@ def main():
         # candidates of every read through one from-sequences submit per batch and the reference's per-read steps behind
         # the refine stage (sort, RemoveLowQualityAlignments, RemoveOverlappingAlignments, StoreMapQVs, -m 4 lines) on host
         # threads while the next batch is on the GPU.  Seeding and clustering (where candidates come from) are not part of it.
-        import subprocess
-        from blasr_amd import build
-        out["end_to_end"] = {"what": "read_harness: candidates from the generator -> gba_submit from sequences (guides made on the device, refine, "
-                                     "pair results only) -> per read sort / filters / mapQV / m4 text; two contexts in turn, 4 batches back to back"}
-        env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
-        for key, argv in (("c2_10kb_1_candidate", ["--reads", "122880", "--cands", "1", "--read-len", "10000", "--ref-len", str(synth.ECOLI_LEN), "--n-frac", "0", "--seed", "2000"]),
-                          ("c4_chr20_10_candidates", ["--reads", "16384", "--cands", "10", "--read-len", "10000", "--ref-len", str(synth.CHR20_LEN), "--n-frac", "0.01", "--seed", "4000"])):
-            try:
-                p = subprocess.run([build.READ_HARNESS] + argv + ["--batches", "4"], env=env, capture_output=True, text=True, timeout=600)
-                out["end_to_end"][key] = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else {"error": (p.stderr or p.stdout)[-300:]}
-            except Exception as e:
-                out["end_to_end"][key] = {"error": repr(e)[:300]}
+        out["end_to_end"] = early["end_to_end"]
         e2 = out["end_to_end"].get("c2_10kb_1_candidate", {})
         if "reads_per_sec" in e2:
             out["end_to_end_reads_per_sec"] = e2["reads_per_sec"]
