@@ -3505,7 +3505,21 @@ int run_device_once(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io
     // first waves), and the last traceback has fewer waves.  Measured on pairs of 10 kb, GCUPS with these parts / with equal
     // parts of about part_pairs (tools/run_shape2.sh): 245 760 pairs 796 / 707, 307 200: 813 / 796, 368 640: 821-842 / 788,
     // 491 520: 856-875 / 823-850, 614 400: 881 / 848; parts below 90 000 pairs lose (fewer than 1.4 waves per SIMD).
-    std::vector<uint32_t> bound;
+    // (on the stack for up to 31 parts: the entry point that allocates nothing runs one part and must not touch the heap either)
+    struct Bounds {
+        uint32_t small[32];
+        std::vector<uint32_t> big;
+        uint32_t count = 0;
+        void push_back(uint32_t x)
+        {
+            if (big.empty() && count < 32u) small[count] = x;
+            else { if (big.empty()) big.assign(small, small + count); big.push_back(x); }
+            count++;
+        }
+        uint32_t operator[](uint32_t i) const { return big.empty() ? small[i] : big[i]; }
+        uint32_t back() const { return (*this)[count - 1u]; }
+        uint32_t size() const { return count; }
+    } bound;
     {
         bound.push_back(0);
         std::vector<uint32_t> shape;
