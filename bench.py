@@ -22,9 +22,12 @@ Beside the device-resident rate (`value`) the line carries, on rank 0 at N=1:
   host_to_host  the same batch through gba_submit / gba_wait from and to page-locked
                 host memory (targets as windows of the resident reference)
   cpu_baseline  the CPU oracle on all host cores over a bounded sample of the batch
-  other_workloads  BASELINE configs 3, 4 and 5 device-resident, two steps each; for the one-part batches (3, 5) also streamed through four contexts
+  other_workloads  BASELINE configs 3, 4 and 5 device-resident, two steps each; for the one-part batches (3, 5) also streamed
+                through four contexts; the default read set with a quality-value cost profile, and under the Local end rule
   streamed      the same batch streamed through two contexts by two threads (device-resident)
   end_to_end    reads in, filtered and scored alignments out (read-level harness)
+host_to_host and end_to_end are measured by processes of their own, which run first, before this process touches the
+GPU (host_legs_first); everything else follows the timed steps.
 
 Prints ONE JSON line on rank 0.
 """
