@@ -579,6 +579,10 @@ def main():
             "fill_gcups": round(cells_step / fill_s / 1e9, 2),
             "traffic": traffic,
             "alone": alone,
+            # what inline-asm chains of single instructions reach on the box (tools/exp/valu.hip, two waves per SIMD and more):
+            # the nominal peak above is not reachable by the instruction mix of the recurrence
+            "measured_issue_rates_tops": {"v_add_u32 / v_and_b32 / v_mov_b32": 64.0, "v_min3_i32 / v_perm_b32 / v_lshl_add_u32 / v_bfi_b32 / v_bfe_u32": 36.0,
+                                          "frac_of_v_add_rate": round(cells_step * ops_cell / fill_s / 1e12 / 64.0, 4)},
         },
         "roofline_hbm": {
             "bound": "hbm", "kernel": kernel,
