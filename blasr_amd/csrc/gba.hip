@@ -3523,6 +3523,16 @@ int run_device_once(gba_ctx *c, const gba_batch *b, gba_results *out, HostIO *io
     {
         bound.push_back(0);
         std::vector<uint32_t> shape;
+        if (io && !c->part_shape.empty() && getenv("GBA_PART_SHAPE_HOST")) shape = c->part_shape;       // experiments
+        // A host-buffer batch of one part has nothing to move its copies under: from about half a part on it runs as two halves
+        // (as long as the halves stay on the lane classes), so that the second half's inputs and the first half's results
+        // travel under the other half's kernels.  Two contexts in turn on pairs of 10 kb, GCUPS as halves / in one part:
+        // 49 152 pairs 411 / 393, 65 536: 447 / 390, 98 304: 538 / 452, 122 880: 539 / 398 (32 768: 213 / 328).
+        if (io && shape.empty() && parts == 1 && c->part_pairs && n >= c->part_pairs * 2 / 5) {
+            const bool aff = c->sc.mode == GBA_MODE_AFFINE;
+            const uint32_t lanes_from = aff ? (b->q_profile ? c->wave_pairs_affine_prof : c->wave_pairs_affine) : c->wave_pairs;
+            if (n / 2 >= lanes_from) shape = {1, 1};
+        }
         if (!io && !c->fixed_on && c->part_pairs) {
             if (!c->part_shape.empty()) shape = c->part_shape;       // experiments: parts in the proportions of GBA_PART_SHAPE
             else if (c->shape_parts && c->alone_on_device && parts >= 2) {

@@ -564,6 +564,42 @@ def test_batches_in_parts(api, oracle, synth, monkeypatch, part):
         c2.close()
 
 
+@pytest.mark.parametrize("wave_pairs,n", [("100", 400), ("100", 250), ("300", 400)])
+def test_host_batch_of_one_part_runs_as_two_halves(api, oracle, synth, monkeypatch, wave_pairs, n):
+    """A host-buffer batch of 2/5 of a part and more, which would be one part, runs as two halves when the halves still
+    reach the lane classes (400 and 250 pairs of parts of 600 with lanes from 100 pairs); otherwise in one piece (lanes
+    from 300): results and the packed block arena are the oracle's either way, and a small arena fails the same pairs."""
+    monkeypatch.setenv("GBA_PART_PAIRS", "600")
+    monkeypatch.setenv("GBA_WAVE_PAIRS", wave_pairs)
+    monkeypatch.setenv("GBA_WAVE_PAIRS_AFFINE", wave_pairs)
+    c2 = api.Context(0, timing=True)
+    try:
+        batch = synth.generate(n, read_len=1200, len_jitter=900, p_ins=0.1, p_del=0.07, seed=89, decoy_every=7)
+        launches = []
+        for kw in (dict(), dict(mode=1, band=16)):
+            _run(c2, api, oracle, batch, **kw)
+            launches.append(c2.timing()["fill_launches"])
+        monkeypatch.setenv("GBA_PART_PAIRS", "0")
+        c1 = api.Context(0, timing=True)
+        try:
+            for i, kw in enumerate((dict(), dict(mode=1, band=16))):
+                _run(c1, api, oracle, batch, **kw)
+                whole = c1.timing()["fill_launches"]              # the batch in one piece: one launch per class
+                assert launches[i] > whole if wave_pairs == "100" else launches[i] == whole
+        finally:
+            c1.close()
+        c2.set_scoring(api.make_scoring())
+        full, fblocks, rc = c2.refine_host(batch)
+        assert rc == 0
+        small, sblocks, rc = c2.refine_host(batch, blocks_capacity=len(fblocks) // 2)
+        assert rc == -4 and c2.blocks_needed == len(fblocks)
+        fits = full["blk_off"].astype(np.int64) + full["n_blk"] <= len(fblocks) // 2
+        ok = full["status"] == 0
+        assert (small["status"][ok & ~fits] == 4).all() and (small["status"][ok & fits] == 0).all()
+    finally:
+        c2.close()
+
+
 @pytest.mark.parametrize("edge,part", [("1", "128"), ("1", "600"), ("1", "400"), ("0", "128")])
 def test_device_batches_with_small_first_and_last_parts(api, synth, monkeypatch, edge, part):
     """A context that has the GPU to itself cuts a device-resident batch into parts of its own shape (two halves, or

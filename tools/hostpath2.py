@@ -29,7 +29,10 @@ for i in range(a.ctxs):
 t0 = time.perf_counter()
 submit(0)
 for k in range(a.batches):
-    if k + 1 < a.batches:
+    if a.ctxs == 1:                       # one context: one batch in flight
+        if k > 0:
+            submit(k)
+    elif k + 1 < a.batches:
         submit(k + 1)
     rc, needed = ctxs[k % a.ctxs].wait_host()
     assert rc == 0
