@@ -99,6 +99,35 @@ def test_one_call_equals_two_calls(api, oracle, synth):
         ctx.close()
 
 
+def test_one_call_on_a_batch_that_runs_as_two_halves(api, synth, monkeypatch):
+    """A host batch from sequences whose refine stage runs as two halves (400 pairs where a part is 600 and the lane
+    classes begin at 100): one call equals two calls, with a block arena and to intervals only, and equals the same
+    batch refined in one piece."""
+    monkeypatch.setenv("GBA_WAVE_PAIRS", "100")
+    monkeypatch.setenv("GBA_PART_PAIRS", "0")
+    whole = api.Context(0)
+    monkeypatch.setenv("GBA_PART_PAIRS", "600")
+    ctx = api.Context(0)
+    try:
+        batch = synth.generate(400, read_len=1500, seed=1818, len_jitter=900, decoy_every=9)
+        seqs = _sequences_only(batch)
+        sp = api.make_sdp_params()
+        for c in (ctx, whole):
+            c.set_scoring(api.make_scoring())
+        status, want, want_blocks = _two_calls(ctx, seqs, sp)
+        assert (status == 0).sum() > 50 and (status != 0).any()
+        for c in (ctx, whole):
+            c.set_guide_producer(sp)
+            got, got_blocks, rc = c.refine_host(seqs)
+            assert rc == 0
+            _same(status, want, want_blocks, got, got_blocks)
+            only, rc = c.refine_host_intervals(seqs)
+            assert rc == 0 and only.tobytes() == got.tobytes()
+    finally:
+        ctx.close()
+        whole.close()
+
+
 def test_windows_of_the_reference_in_parts_to_intervals(api, synth, monkeypatch):
     """Reads and windows of the resident reference on both strands, a batch run in several parts, no block
     arena: sequences in, interval records out; and the device entry point on the same batch."""
