@@ -43,8 +43,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 # A context runs the parts of a batch on a dozen streams (three slots of a main and two auxiliary streams, two copy
 # streams).  With HIP's default of four hardware queues streams share queues and one part's guide construction waits
 # behind another part's fill; the library's callers are told to raise it, and so does this program,
-# before the HIP runtime starts.
-os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("GBA_BENCH_HW_QUEUES", "16")      # (the GPU boxes export the default, 4)
+# before the HIP runtime starts.  Twenty: two contexts' kernel streams then find queues of their own (the same batch
+# streamed through two contexts 913-924 GCUPS against 880-883 with sixteen), and the process stays below the number
+# from which everything slows down (24 and 32: the contexts made later in the process ran at 55-75 % of their rate).
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("GBA_BENCH_HW_QUEUES", "20")      # (the GPU boxes export the default, 4)
 sys.path.insert(0, ROOT)
 
 # HBM bytes of one step's fill launches at the default workload, from separate rocprofv3 --pmc passes of
@@ -649,13 +651,16 @@ def main():
         ctx.refine_device(dbatch, out_pairs, out_blocks)
         torch.cuda.synchronize()
 
+    # The headline context goes before the other configurations make theirs: its eleven streams would keep their places on
+    # the hardware queues, and a later context's streams then share queues among themselves (a part's second fill launch
+    # queued behind the previous part's traceback: C4 572-583 GCUPS instead of 712-719).
+    digest = results_digest(res, out_blocks[:needed_dev[0]].cpu().numpy()) if rank == 0 and world == 1 and not args.no_host else None
+    del dbatch, out_blocks, out_pairs
+    ctx.close()
+    torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_host:
         # The same batch from host memory to host memory (gba_submit / gba_wait), measured by a child process before this
         # one touched the GPU: see host_child() and host_legs_first().
-        digest = results_digest(res, out_blocks[:needed_dev[0]].cpu().numpy())
-        del dbatch, out_blocks, out_pairs
-        ctx.close()
-        torch.cuda.empty_cache()
         p = early["host_child"]
         if p.returncode != 0:
             out["host_to_host"] = {"error": (p.stderr or p.stdout)[-400:]}

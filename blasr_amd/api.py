@@ -496,7 +496,8 @@ class DevicePipeline:
     runs: the first packing and guide of one batch and the last traceback of the other run under fills instead of alone,
     and a batch of a single part (too few pairs to be cut) no longer has its traceback to itself.  Measured: 491 520
     pairs of 10 kb 830 -> 890-903 GCUPS, 16 384 affine pairs of 20 kb 193 -> 256-262.  Every context holds its own scratch.
-    Set GPU_MAX_HW_QUEUES=16 in the environment before the HIP runtime starts."""
+    Set GPU_MAX_HW_QUEUES=20 in the environment before the HIP runtime starts (two contexts' kernel
+    streams then have queues of their own; 24 and more slowed every later context of the process down)."""
 
     def __init__(self, device=0, depth=2, contexts=()):
         """contexts: contexts of this GPU the caller already has (they keep their scoring, reference and scratch and stay
