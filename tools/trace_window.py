@@ -1,5 +1,5 @@
 """Launch timeline of the kernels in front of the first launch of a given kernel in a rocprofv3 kernel trace:
-usage: trace_window.py r_kernel_trace.csv <kernel-name-substring> <k_results_init launches to go back>."""
+usage: trace_window.py r_kernel_trace.csv <kernel-name-substring | END> <k_results_init launches to go back>."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = []
@@ -9,7 +9,7 @@ for r in rows:
         continue
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "k_" + n.split("k_")[1].split("(")[0], r["Queue_Id"], r["Stream_Id"]))
 ev.sort()
-stop = next(i for i, e in enumerate(ev) if sys.argv[2] in e[2])
+stop = len(ev) if sys.argv[2] == "END" else next(i for i, e in enumerate(ev) if sys.argv[2] in e[2])
 inits = [i for i, e in enumerate(ev[:stop]) if e[2] == "k_results_init"]
 s = inits[-int(sys.argv[3])]
 while ev[s][2] != "k_meta":
