@@ -1,6 +1,6 @@
 """Is the length of a one-part batch's traceback tail a property of the context?  Several contexts alive at once, each
 with its own scratch and streams, run the same device-resident batch (122 880 pairs of 10 kb, Local end rule) in turn,
-three rounds: per context and round the step, the fill and the tail (gba_timing).  usage: tail_modes.py [contexts = 5]"""
+three rounds: per context and round the step, the fill and the tail (gba_timing).  usage: tail_modes.py [contexts = 5] [pairs = 122880]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench                                   # sets GPU_MAX_HW_QUEUES before the runtime starts
@@ -9,7 +9,7 @@ import torch
 from blasr_amd import api, synth, _lib
 
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-n = 122880
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 122880
 cfg = dict(synth.PRESETS["c2_10kb_linear"])
 ref = synth.reference(cfg["ref_len"], synth.REF_SEED, cfg.get("n_frac", 0.0))
 host = synth.generate(n, ref=ref, **{a: b for a, b in cfg.items() if a != "ref"})
